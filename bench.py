@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the PML / col-ID query path on MI355X.
+
+Metric (BASELINE.json): query bases/s on a 64-haplotype-scale synthetic index
+(~200 M rows) with 150 bp reads, 10 M reads per GPU, at 1/2/4/8 GPUs (weak
+scaling: reads shard across ranks, the index is replicated in every HBM, the
+.pml/.cid blocks are gathered to rank 0 over RCCL).
+
+A "step" = one pass of the query over this rank's whole read batch, inputs and
+outputs resident in HBM (for N > 1 it includes the RCCL gather, pipelined in
+chunks behind the compute).  One JSON line on rank 0.
+
+    python bench.py                       # N=1, C2 workload
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+
+`--rows/--reads/--read-len` shrink the workload for rehearsals (the line then
+names the smaller workload; only the default is the BASELINE configuration).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_BASE = 27
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=200_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--sub-permille", type=int, default=10)
+    ap.add_argument("--chunks", type=int, default=0, help="pipeline chunks per step (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = load_package()
+    m = args.read_len
+    n_reads = args.reads
+    n_bases = n_reads * m
+
+    # ---- the index: synthesised on the host in the reference's on-disk format,
+    #      loaded through the C-ABI (upload + device re-layout)
+    t0 = time.time()
+    image = pkg.synth_index(args.rows, mean_len=8, split_permille=0, seed=42)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    tbl = pkg.ColPml.from_bytes(image, device=local_rank)
+    t_load = time.time() - t0
+    info = tbl.info()
+
+    # ---- this rank's reads, sampled on the device by backward walk (seed differs per rank)
+    d_bases = torch.zeros(n_bases + 32, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    tbl.synth_reads_device(n_reads, m, args.sub_permille, 43 + rank, d_bases.data_ptr(), d_off.data_ptr(),
+                           stream.cuda_stream)
+    d_pml = torch.zeros(n_bases + 8, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(n_bases + 8, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    # ---- gather destination on rank 0 (byte views; u16 PML travels as 2 bytes)
+    n_chunks = args.chunks or (1 if world == 1 else 4)
+    bounds = [n_reads * c // n_chunks for c in range(n_chunks + 1)]
+    pml_bytes = d_pml.view(torch.uint8)
+    if world > 1 and rank == 0:
+        g_pml = torch.empty((world, 2 * n_bases), dtype=torch.uint8, device=dev)
+        g_cid = torch.empty((world, n_bases), dtype=torch.uint8, device=dev)
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    kernel_events = []
+
+    def step(record):
+        works = []
+        for c in range(n_chunks):
+            lo, hi = bounds[c], bounds[c + 1]
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
+                             d_pml.data_ptr(), d_cid.data_ptr(), 2, stream.cuda_stream)
+            if record:
+                e1.record(stream)
+                kernel_events.append((e0, e1))
+            if world > 1:
+                done = torch.cuda.Event()
+                done.record(stream)
+                with torch.cuda.stream(comm_stream):
+                    comm_stream.wait_event(done)
+                    for src, dst, scale in ((pml_bytes, g_pml if rank == 0 else None, 2),
+                                            (d_cid, g_cid if rank == 0 else None, 1)):
+                        piece = src[scale * lo * m: scale * hi * m]
+                        glist = [dst[r, scale * lo * m: scale * hi * m] for r in range(world)] if rank == 0 else None
+                        works.append(dist.gather(piece, glist, dst=0, async_op=True))
+        for w in works:
+            w.wait()
+        if comm_stream is not None:
+            stream.wait_stream(comm_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
+    launches = len(kernel_ms)
+    avg_launch_ms = sum(kernel_ms) / max(launches, 1)
+    bases_per_launch = n_bases / n_chunks
+
+    out = None
+    if rank == 0:
+        value = world * n_bases * args.steps / elapsed
+        achieved = ALG_BYTES_PER_BASE * bases_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        is_baseline_cfg = (args.rows, args.reads, args.read_len) == (200_000_000, 10_000_000, 150)
+        if is_baseline_cfg and n_chunks == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "query bases/s", "value": value, "unit": "bases/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": f"{info.r} row synthetic .col_pml (n={info.n}), {n_reads}x{m} bp "
+                                   f"backward-walk reads per GPU, {args.sub_permille / 10:.1f}% substitutions"
+                                   + ("" if is_baseline_cfg else " [REDUCED rehearsal size]"),
+                       "rows": int(info.r), "reads_per_gpu": n_reads, "read_len": m,
+                       "parallelism": f"reads sharded x{world}, index replicated, RCCL gather to rank 0"
+                       if world > 1 else "single GPU",
+                       "pipeline_chunks": n_chunks,
+                       "index_gen_s": round(t_gen, 2), "index_load_s": round(t_load, 2),
+                       "index_hbm_bytes": int(info.device_bytes)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "pml_query_kernel<u16>", "avg_launch_ms": avg_launch_ms,
+                         "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
+                         "bases_per_launch": bases_per_launch},
+        }
+
+    # ---- CPU baseline: the oracle (a port, the reference itself cannot travel) on a
+    #      bounded sample of rank 0's reads, 1 thread (the reference's threading model,
+    #      pml_query.cpp:74) and all host cores; doubles as an on-box parity check.
+    if rank == 0 and world == 1 and not args.no_cpu:
+        oracle = load_oracle()
+        ref = oracle.OracleIndex(image)
+        cores = len(os.sched_getaffinity(0))
+
+        def run_sample(k, threads):
+            hb = d_bases[:k * m].cpu().numpy()
+            ho = np.arange(k + 1, dtype=np.uint64) * np.uint64(m)
+            t1 = time.perf_counter()
+            p, c = ref.query_batch(hb, ho, threads=threads)
+            return time.perf_counter() - t1, p, c
+
+        probe_k = min(n_reads, 4000)
+        dt, _, _ = run_sample(probe_k, 1)
+        rate1 = probe_k * m / dt
+        k1 = int(min(n_reads, max(probe_k, rate1 * args.cpu_seconds * 0.5 / m)))
+        dt1, p1, c1 = run_sample(k1, 1)
+        kall = int(min(n_reads, max(k1, (k1 * m / dt1) * cores * 0.5 * args.cpu_seconds * 0.5 / m)))
+        dta, pa, ca = run_sample(kall, cores)
+        gp = d_pml[:kall * m].cpu().numpy().view(np.uint16)
+        gc = d_cid[:kall * m].cpu().numpy()
+        parity = bool(np.array_equal(gp, pa) and np.array_equal(gc, ca)
+                      and np.array_equal(gp[:k1 * m], p1) and np.array_equal(gc[:k1 * m], c1))
+        resets = float((pa == 0).mean())
+        out["cpu_baseline"] = {
+            "value": k1 * m / dt1, "unit": "bases/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/colbwt_oracle.c on the first {k1} reads of the same batch ({k1 * m} bases, "
+                      f"{dt1:.1f} s), same {info.r}-row index in host memory",
+            "all_cores": {"value": kall * m / dta, "cores": cores, "reads": kall, "seconds": round(dta, 2)},
+            "gpu_matches_oracle_on_sample": parity, "reset_fraction": resets,
+        }
+        if not parity:
+            out["error"] = "GPU output differs from the oracle on the CPU sample"
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if out is None or "error" not in out else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

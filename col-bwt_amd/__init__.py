@@ -1,0 +1,178 @@
+"""colbwt_amd -- host-side Python mirror of the reference's query interface
+(`col_pml`, include/col_bwt.hpp:386-575; `pml_query`, src/pml_query.cpp) over
+the MI355X-native C-ABI library `libcolbwt.so` (include/colbwt.h).
+
+This module is plumbing: ctypes over the C-ABI.  All computation happens in
+the hand-written HIP kernels of `csrc/`.  There is no CPU fallback: if the
+library is missing or no HIP device is usable, calls raise `ColbwtError`.
+
+The directory is named `col-bwt_amd` (not importable by that name); load it
+with `__graft_entry__.load_package()` which registers it as `colbwt_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcolbwt.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "colbwt.h")
+
+# every symbol include/colbwt.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
+    "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
+    "colbwt_query_device", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
+    "colbwt_synth_reads_device",
+)
+
+
+class ColbwtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"colbwt error {code}: {msg}")
+        self.code = code
+
+
+class Info(C.Structure):
+    _fields_ = [("bwt_r", C.c_uint64), ("n", C.c_uint64), ("r", C.c_uint64), ("sigma", C.c_uint32),
+                ("device", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("h2d_ms", C.c_double),
+                ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("algorithmic_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads libcolbwt.so; raises loudly when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ColbwtError(-100, f"{LIB_PATH} not built: run __graft_entry__.build() "
+                                "(the query path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.colbwt_version.restype = C.c_char_p
+    L.colbwt_last_error.restype = C.c_char_p
+    L.colbwt_index_open.argtypes = [C.c_char_p, vp, i32, C.POINTER(vp)]
+    L.colbwt_index_open_memory.argtypes = [vp, u64, vp, i32, C.POINTER(vp)]
+    L.colbwt_index_close.argtypes = [vp]
+    L.colbwt_index_close.restype = None
+    L.colbwt_index_info.argtypes = [vp, C.POINTER(Info)]
+    L.colbwt_query_batch.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(Stats)]
+    L.colbwt_query_batch_u32.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(Stats)]
+    L.colbwt_query_device.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, C.POINTER(Stats)]
+    L.colbwt_query_file.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.POINTER(Stats)]
+    L.colbwt_synth_index_bytes.argtypes = [u64]
+    L.colbwt_synth_index_bytes.restype = u64
+    L.colbwt_synth_index.argtypes = [u64, C.c_uint32, C.c_uint32, u64, vp, u64]
+    L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise ColbwtError(rc, lib().colbwt_last_error().decode("utf-8", "replace"))
+
+
+def version():
+    return lib().colbwt_version().decode()
+
+
+class ColPml:
+    """The reference's `col_pml` (col_bwt.hpp:386): load an index, query reads.
+
+    `ColPml.load(prefix)` <-> `col_pml tbl; tbl.load(ifstream(prefix + ".col_pml"))`
+    (pml_query.cpp:109-112); `query_pml(pattern)` <-> col_bwt.hpp:403-412.
+    """
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, prefix_or_file, device=0):
+        h = C.c_void_p()
+        _check(lib().colbwt_index_open(os.fsencode(prefix_or_file), None, int(device), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_bytes(cls, image, device=0):
+        arr = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8))
+        h = C.c_void_p()
+        _check(lib().colbwt_index_open_memory(arr.ctypes.data, arr.size, None, int(device), C.byref(h)))
+        return cls(h)
+
+    def info(self):
+        out = Info()
+        _check(lib().colbwt_index_info(self._h, C.byref(out)))
+        return out
+
+    # -- col_pml::query_pml(const char*, size_t), col_bwt.hpp:409-412 ---------
+    def query_pml(self, pattern):
+        """One read -> (pml, cid) uint64 arrays, index k <-> pattern[k]."""
+        p = np.frombuffer(bytes(pattern), dtype=np.uint8)
+        off = np.array([0, p.size], dtype=np.uint64)
+        pml, cid, _ = self.query_batch(p, off, wide=p.size > 65535)
+        return pml.astype(np.uint64), cid.astype(np.uint64)
+
+    def query_batch(self, bases, read_off, wide=False):
+        """Many reads at once (host buffers in, host buffers out)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        n_reads = read_off.size - 1
+        total = int(read_off[-1]) if n_reads >= 0 and read_off.size else 0
+        pml = np.zeros(total, np.uint32 if wide else np.uint16)
+        cid = np.zeros(total, np.uint8)
+        st = Stats()
+        fn = lib().colbwt_query_batch_u32 if wide else lib().colbwt_query_batch
+        _check(fn(self._h, bases.ctypes.data, read_off.ctypes.data, max(n_reads, 0),
+                  pml.ctypes.data, cid.ctypes.data, C.byref(st)))
+        return pml, cid, st
+
+    def query_device(self, d_bases, d_read_off, n_reads, n_bases, d_pml, d_cid, pml_bytes=2,
+                     stream=0, timed=False):
+        """Device-resident entry point: arguments are raw device pointers (ints)."""
+        st = Stats()
+        _check(lib().colbwt_query_device(self._h, d_bases, d_read_off, n_reads, n_bases, d_pml,
+                                         pml_bytes, d_cid, stream, C.byref(st) if timed else None))
+        return st
+
+    # -- pml_query main, vec mode (pml_query.cpp:92-143) ----------------------
+    def query_file(self, pattern_path, pml_path=None, cid_path=None, batch_bases=0):
+        st = Stats()
+        _check(lib().colbwt_query_file(self._h, os.fsencode(pattern_path),
+                                       os.fsencode(pml_path) if pml_path else None,
+                                       os.fsencode(cid_path) if cid_path else None,
+                                       batch_bases, C.byref(st)))
+        return st
+
+    def synth_reads_device(self, n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream=0):
+        _check(lib().colbwt_synth_reads_device(self._h, n_reads, read_len, sub_permille, seed,
+                                               d_bases, d_read_off, stream))
+
+    def close(self):
+        if self._h:
+            lib().colbwt_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_index(rows, mean_len=8, split_permille=0, seed=42):
+    """Synthetic `.col_pml` image (SURVEY.md 8(d) recipe) as a uint8 numpy array."""
+    nbytes = lib().colbwt_synth_index_bytes(rows)
+    out = np.empty(nbytes, np.uint8)
+    _check(lib().colbwt_synth_index(rows, mean_len, split_permille, seed, out.ctypes.data, nbytes))
+    return out

@@ -1,0 +1,336 @@
+// capi.hip -- the C-ABI of include/colbwt.h over the HIP engine.
+// Host-side mirror of col_pml (col_bwt.hpp:386-575) and of pml_query's main
+// (pml_query.cpp:92-143).  No CPU fallback anywhere: every entry point that
+// computes PML/col-ids needs a HIP device and says so when there is none.
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/colbwt.h"
+#include "fastx_reader.h"
+#include "index.h"
+#include "query_kernels.h"
+#include "text_writer.h"
+
+using namespace colbwt;
+
+struct colbwt_index {
+    Index ix;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define API_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            rc = fail(e_ == hipErrorOutOfMemory ? COLBWT_ERR_NOMEM : COLBWT_ERR_HIP,          \
+                      std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+            goto done;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+bool widths_ok(const colbwt_widths *w) {
+    return !w || (w->bwt_bytes == 5 && w->run_bytes == 4 && w->len_bytes == 2 && w->id_bits == 8);
+}
+
+struct MappedFile {
+    const uint8_t *data = nullptr;
+    uint64_t len = 0;
+    int fd = -1;
+    ~MappedFile() {
+        if (data && len) munmap((void *)data, len);
+        if (fd >= 0) close(fd);
+    }
+    bool open(const std::string &path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+        len = (uint64_t)st.st_size;
+        if (len == 0) return true;
+        void *p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) return false;
+        data = (const uint8_t *)p;
+        return true;
+    }
+};
+
+template <typename PmlT>
+int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, PmlT *pml,
+                     uint8_t *cid, colbwt_stats *stats) {
+    if (!idx) return fail(COLBWT_ERR_ARG, "null index");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n_reads == 0) return COLBWT_OK;
+    if (!read_off) return fail(COLBWT_ERR_ARG, "null read_off");
+    if (read_off[0] != 0) return fail(COLBWT_ERR_ARG, "read_off[0] must be 0");
+    uint64_t max_len = 0;
+    for (uint64_t k = 0; k < n_reads; ++k) {
+        if (read_off[k + 1] < read_off[k]) return fail(COLBWT_ERR_ARG, "read_off not non-decreasing");
+        max_len = std::max(max_len, read_off[k + 1] - read_off[k]);
+    }
+    const uint64_t n_bases = read_off[n_reads];
+    if (sizeof(PmlT) == 2 && max_len > 65535)
+        return fail(COLBWT_ERR_ARG, "read longer than 65535 bases: use colbwt_query_batch_u32");
+    if (max_len > 0xFFFFFFFFull) return fail(COLBWT_ERR_ARG, "read longer than 2^32-1 bases");
+    if (n_bases == 0) {
+        if (stats) stats->n_reads = n_reads;
+        return COLBWT_OK;
+    }
+    if (!bases || !pml || !cid) return fail(COLBWT_ERR_ARG, "null bases/pml/cid");
+
+    int rc = select_device(idx->ix.device(), g_err);
+    if (rc != COLBWT_OK) return rc;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint8_t *d_bases = nullptr, *d_cid = nullptr;
+    uint64_t *d_off = nullptr;
+    PmlT *d_pml = nullptr;
+    const uint64_t bases_alloc = (n_bases + 16 + 15) & ~15ull;
+    float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
+
+    API_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto &e : ev) API_HIP(hipEventCreate(&e));
+    API_HIP(hipMalloc((void **)&d_bases, bases_alloc));
+    API_HIP(hipMalloc((void **)&d_off, (n_reads + 1) * sizeof(uint64_t)));
+    API_HIP(hipMalloc((void **)&d_pml, ((n_bases + 7) & ~7ull) * sizeof(PmlT)));
+    API_HIP(hipMalloc((void **)&d_cid, (n_bases + 7) & ~7ull));
+
+    API_HIP(hipEventRecord(ev[0], stream));
+    API_HIP(hipMemsetAsync(d_bases + (bases_alloc - 32), 0, 32, stream));
+    API_HIP(hipMemcpyAsync(d_bases, bases, n_bases, hipMemcpyHostToDevice, stream));
+    API_HIP(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    API_HIP(hipEventRecord(ev[1], stream));
+    launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, stream);
+    API_HIP(hipGetLastError());
+    API_HIP(hipEventRecord(ev[2], stream));
+    API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
+    API_HIP(hipMemcpyAsync(cid, d_cid, n_bases, hipMemcpyDeviceToHost, stream));
+    API_HIP(hipEventRecord(ev[3], stream));
+    API_HIP(hipStreamSynchronize(stream));
+    API_HIP(hipEventElapsedTime(&ms_h2d, ev[0], ev[1]));
+    API_HIP(hipEventElapsedTime(&ms_k, ev[1], ev[2]));
+    API_HIP(hipEventElapsedTime(&ms_d2h, ev[2], ev[3]));
+    if (stats) {
+        stats->n_reads = n_reads;
+        stats->n_bases = n_bases;
+        stats->h2d_ms = ms_h2d;
+        stats->kernel_ms = ms_k;
+        stats->d2h_ms = ms_d2h;
+        stats->algorithmic_bytes = n_bases * (uint64_t)kAlgBytesPerBase;
+    }
+    rc = COLBWT_OK;
+done:
+    if (d_bases) (void)hipFree(d_bases);
+    if (d_off) (void)hipFree(d_off);
+    if (d_pml) (void)hipFree(d_pml);
+    if (d_cid) (void)hipFree(d_cid);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *colbwt_version(void) { return "colbwt-mi355x 0.1.0 (gfx950)"; }
+
+const char *colbwt_last_error(void) { return g_err.c_str(); }
+
+int colbwt_index_open_memory(const void *bytes, uint64_t len, const colbwt_widths *widths, int device,
+                             colbwt_index **out) {
+    if (!out) return fail(COLBWT_ERR_ARG, "null out");
+    *out = nullptr;
+    if (!widths_ok(widths))
+        return fail(COLBWT_ERR_ARG, "only the shipped widths BWT_BYTES=5 RUN_BYTES=4 LEN_BYTES=2 ID_BITS=8 are supported");
+    colbwt_index *idx = new (std::nothrow) colbwt_index();
+    if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
+    std::string err;
+    int rc = idx->ix.load((const uint8_t *)bytes, len, device, err);
+    if (rc != COLBWT_OK) {
+        delete idx;
+        return fail(rc, err);
+    }
+    *out = idx;
+    return COLBWT_OK;
+}
+
+int colbwt_index_open(const char *prefix_or_file, const colbwt_widths *widths, int device, colbwt_index **out) {
+    if (!prefix_or_file || !out) return fail(COLBWT_ERR_ARG, "null argument");
+    *out = nullptr;
+    // pml_query.cpp:110-111: filename = prefix + ".col_pml" (col_bwt.hpp:434-437)
+    MappedFile mf;
+    std::string path = std::string(prefix_or_file) + ".col_pml";
+    if (!mf.open(path)) {
+        MappedFile direct;
+        path = prefix_or_file;
+        if (!direct.open(path))
+            return fail(COLBWT_ERR_IO, std::string("cannot open ") + prefix_or_file + ".col_pml (or " + prefix_or_file + ")");
+        return colbwt_index_open_memory(direct.data, direct.len, widths, device, out);
+    }
+    return colbwt_index_open_memory(mf.data, mf.len, widths, device, out);
+}
+
+void colbwt_index_close(colbwt_index *idx) { delete idx; }
+
+int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
+    if (!idx || !out) return fail(COLBWT_ERR_ARG, "null argument");
+    out->bwt_r = idx->ix.bwt_r();
+    out->n = idx->ix.n();
+    out->r = idx->ix.r();
+    out->sigma = idx->ix.sigma();
+    out->device = (uint32_t)idx->ix.device();
+    out->device_bytes = idx->ix.device_bytes();
+    return COLBWT_OK;
+}
+
+int colbwt_query_batch(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                       uint16_t *pml, uint8_t *cid, colbwt_stats *stats) {
+    return query_batch_host<uint16_t>(idx, bases, read_off, n_reads, pml, cid, stats);
+}
+
+int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                           uint32_t *pml, uint8_t *cid, colbwt_stats *stats) {
+    return query_batch_host<uint32_t>(idx, bases, read_off, n_reads, pml, cid, stats);
+}
+
+int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                        uint64_t n_bases, void *d_pml, int pml_bytes, uint8_t *d_cid, void *hip_stream,
+                        colbwt_stats *stats) {
+    if (!idx) return fail(COLBWT_ERR_ARG, "null index");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (pml_bytes != 2 && pml_bytes != 4) return fail(COLBWT_ERR_ARG, "pml_bytes must be 2 or 4");
+    if (n_reads == 0) return COLBWT_OK;
+    if (!d_bases || !d_read_off || !d_pml || !d_cid) return fail(COLBWT_ERR_ARG, "null device pointer");
+    if (((uintptr_t)d_bases & 15) || ((uintptr_t)d_pml & 15) || ((uintptr_t)d_cid & 7))
+        return fail(COLBWT_ERR_ARG, "d_bases/d_pml must be 16-byte aligned and d_cid 8-byte aligned");
+    int rc = select_device(idx->ix.device(), g_err);
+    if (rc != COLBWT_OK) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (stats) {
+        API_HIP(hipEventCreate(&e0));
+        API_HIP(hipEventCreate(&e1));
+        API_HIP(hipEventRecord(e0, stream));
+    }
+    launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, stream);
+    API_HIP(hipGetLastError());
+    if (stats) {
+        API_HIP(hipEventRecord(e1, stream));
+        API_HIP(hipEventSynchronize(e1));
+        API_HIP(hipEventElapsedTime(&ms, e0, e1));
+        stats->n_reads = n_reads;
+        stats->n_bases = n_bases;
+        stats->kernel_ms = ms;
+        stats->algorithmic_bytes = n_bases * (uint64_t)kAlgBytesPerBase;
+    }
+    rc = COLBWT_OK;
+done:
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path, const char *cid_path,
+                      uint64_t batch_bases, colbwt_stats *stats) {
+    if (!idx || !pattern_path) return fail(COLBWT_ERR_ARG, "null argument");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (batch_bases == 0) batch_bases = 64ull << 20;
+    // pml_query.cpp:124-125
+    const std::string pml_name = pml_path ? pml_path : std::string(pattern_path) + ".pml";
+    const std::string cid_name = cid_path ? cid_path : std::string(pattern_path) + ".cid";
+    FastxReader reader;
+    if (!reader.open(pattern_path)) return fail(COLBWT_ERR_IO, std::string("cannot open pattern file ") + pattern_path);
+    TextWriter wp, wc;
+    if (!wp.open(pml_name)) return fail(COLBWT_ERR_IO, "cannot create " + pml_name);
+    if (!wc.open(cid_name)) return fail(COLBWT_ERR_IO, "cannot create " + cid_name);
+
+    std::vector<uint8_t> bases, cid;
+    std::vector<uint64_t> off;
+    std::vector<std::string> names;
+    std::vector<uint16_t> pml16;
+    std::vector<uint32_t> pml32;
+    bool more = true;
+    while (more) {
+        bases.clear();
+        names.clear();
+        off.assign(1, 0);
+        uint64_t max_len = 0;
+        std::string name;
+        while (bases.size() < batch_bases) {  // pml_query.cpp:74 while (patterns.read())
+            if (!reader.next(name, bases)) {
+                more = false;
+                break;
+            }
+            names.push_back(name);
+            max_len = std::max<uint64_t>(max_len, bases.size() - off.back());
+            off.push_back(bases.size());
+        }
+        const uint64_t n_reads = names.size();
+        if (n_reads == 0) break;
+        const uint64_t nb = bases.size();
+        cid.resize(nb);
+        colbwt_stats st{};
+        int rc;
+        const bool wide = max_len > 65535;
+        if (wide) {
+            pml32.resize(nb);
+            rc = colbwt_query_batch_u32(idx, bases.data(), off.data(), n_reads, pml32.data(), cid.data(), &st);
+        } else {
+            pml16.resize(nb);
+            rc = colbwt_query_batch(idx, bases.data(), off.data(), n_reads, pml16.data(), cid.data(), &st);
+        }
+        if (rc != COLBWT_OK) return rc;
+        for (uint64_t k = 0; k < n_reads; ++k) {  // pml_query.cpp:78-85
+            const uint64_t b = off[k], m = off[k + 1] - b;
+            if (wide) wp.record(names[k], pml32.data() + b, m);
+            else wp.record(names[k], pml16.data() + b, m);
+            wc.record(names[k], cid.data() + b, m);
+        }
+        if (stats) {
+            stats->n_reads += st.n_reads;
+            stats->n_bases += st.n_bases;
+            stats->h2d_ms += st.h2d_ms;
+            stats->kernel_ms += st.kernel_ms;
+            stats->d2h_ms += st.d2h_ms;
+            stats->algorithmic_bytes += st.algorithmic_bytes;
+        }
+    }
+    const bool okp = wp.close(), okc = wc.close();
+    if (!okp || !okc) return fail(COLBWT_ERR_IO, "short write on " + pml_name + " / " + cid_name);
+    return COLBWT_OK;
+}
+
+int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
+                              uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, void *hip_stream) {
+    if (!idx || !d_bases || !d_read_off || read_len == 0) return fail(COLBWT_ERR_ARG, "bad argument");
+    int rc = select_device(idx->ix.device(), g_err);
+    if (rc != COLBWT_OK) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 16, stream));
+    launch_synth_reads(idx->ix.table(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
+    API_HIP(hipGetLastError());
+    rc = COLBWT_OK;
+done:
+    return rc;
+}
+
+}  // extern "C"

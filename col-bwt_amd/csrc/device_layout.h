@@ -1,0 +1,49 @@
+// device_layout.h -- HBM layout of the col-bwt run table on MI355X.
+//
+// The on-disk row (col_thr, 18 packed bytes: LF_table.hpp:33-40,
+// col_bwt.hpp:43,84) straddles 64-byte lines and needs
+// the NEXT row's idx for every run length (LF_table.hpp:204-207).  The query
+// is a pure function of BWT positions, so the table
+// is re-laid out once at load time:
+//
+//   rows[r+1]  16-byte aligned rows, one 128-bit load per LF landing:
+//       .x  interval                      (32)   LF_row::interval
+//       .y  offset | len16 << 16          (16+16) LF_row::offset ; run length,
+//                                          0xFFFF = "long": idx[j+1]-idx[j]
+//       .z  idx low 32 bits                      LF_row::idx
+//       .w  idx high 8 | char << 8 | col_id << 16
+//     row r is a sentinel with idx = n, so len(j) = idx[j+1]-idx[j] holds for
+//     the last row too (LF_table.hpp:206 special-cases it).
+//   thr[r]     u64 thresholds (col_thr::threshold), touched only on a mismatch.
+//   next_tbl / prev_tbl  [nblk][sigma] u32: first run >= b*B / last run < b*B
+//     holding each present character; bound the succ_char / pred_char scans
+//     (LF_table.hpp:271-298 are unbounded linear scans) to one block of B rows.
+//   cmap[256]  byte -> dense character index, 0xFF = byte absent from the BWT
+//     (then neither scan can succeed: col_bwt.hpp:533-534,572-573).
+#pragma once
+#include <stdint.h>
+
+#include "disk_format.h"
+
+namespace colbwt {
+
+constexpr uint32_t kLenLong = 0xFFFFu;      // len16 escape
+constexpr uint32_t kNone = 0xFFFFFFFFu;     // "no such run" in jump tables
+constexpr uint32_t kBlockShift = 8;         // B = 256 rows per jump block
+constexpr uint32_t kAbsent = 0xFFu;         // cmap: byte not in the BWT
+constexpr uint32_t kAlgBytesPerBase = 27;
+
+struct DevTable {
+    const uint4 *rows;        // r + 1
+    const uint64_t *thr;      // r
+    const uint32_t *next_tbl; // nblk * sigma
+    const uint32_t *prev_tbl; // nblk * sigma
+    const uint8_t *cmap;      // 256
+    uint64_t n;
+    uint32_t r;
+    uint32_t sigma;
+    uint32_t nblk;
+    uint32_t pad_;
+};
+
+}  // namespace colbwt

@@ -1,0 +1,49 @@
+// index.h -- the run table resident in HBM (host-side owner object).
+// Mirrors col_pml's load half (col_bwt.hpp:375-380 -> LF_table.hpp:347-357).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "device_layout.h"
+
+namespace colbwt {
+
+struct IndexError {
+    int code;
+    std::string msg;
+};
+
+class Index {
+public:
+    Index() = default;
+    ~Index();
+    Index(const Index &) = delete;
+    Index &operator=(const Index &) = delete;
+
+    // `bytes` is the whole .col_pml image (header + rows) in host memory.
+    // Returns 0 or a COLBWT_ERR_* code with `err` filled.
+    int load(const uint8_t *bytes, uint64_t len, int device, std::string &err);
+
+    const DevTable &table() const { return tbl_; }
+    int device() const { return device_; }
+    uint64_t bwt_r() const { return bwt_r_; }
+    uint64_t n() const { return tbl_.n; }
+    uint64_t r() const { return tbl_.r; }
+    uint32_t sigma() const { return tbl_.sigma; }
+    uint64_t device_bytes() const { return device_bytes_; }
+
+private:
+    void release();
+    DevTable tbl_{};
+    uint64_t bwt_r_ = 0;
+    int device_ = -1;
+    uint64_t device_bytes_ = 0;
+    void *d_rows_ = nullptr, *d_thr_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr, *d_cmap_ = nullptr;
+};
+
+// Selects `device` after checking that a usable gfx950-class HIP device exists.
+int select_device(int device, std::string &err);
+
+}  // namespace colbwt

@@ -1,0 +1,197 @@
+// index.hip -- host side of the loader: .col_pml image -> HBM layout.
+//
+// File format (col_bwt.hpp:360-370 + LF_table.hpp:325-342):
+//   u64 bwt_r, u64 n, u64 r, u64 size, then size raw 18-byte col_thr rows.
+// The reference reads this blindly (UB on a bad file);
+// this loader validates before anything is dereferenced on the device.
+#include "index.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/colbwt.h"
+#include "query_kernels.h"
+
+namespace colbwt {
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            err = std::string(#expr) + ": " + hipGetErrorString(e_);                   \
+            return e_ == hipErrorOutOfMemory ? COLBWT_ERR_NOMEM : COLBWT_ERR_HIP;      \
+        }                                                                              \
+    } while (0)
+
+int select_device(int device, std::string &err) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        err = "no HIP device available (the query path has no CPU fallback)";
+        return COLBWT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        err = "device ordinal " + std::to_string(device) + " out of range (" + std::to_string(count) + " devices)";
+        return COLBWT_ERR_ARG;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return COLBWT_ERR_NO_DEVICE;
+    }
+    return COLBWT_OK;
+}
+
+Index::~Index() { release(); }
+
+void Index::release() {
+    if (device_ >= 0) (void)hipSetDevice(device_);
+    for (void **p : {&d_rows_, &d_thr_, &d_next_, &d_prev_, &d_cmap_}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    device_bytes_ = 0;
+}
+
+static inline uint64_t rd_u64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err) {
+    if (!bytes || len < kHeaderBytes) {
+        err = "index image shorter than its 32-byte header";
+        return COLBWT_ERR_FORMAT;
+    }
+    const uint64_t bwt_r = rd_u64(bytes + 0), n = rd_u64(bytes + 8), r = rd_u64(bytes + 16), size = rd_u64(bytes + 24);
+    if (size != r) {
+        err = "header: vector size " + std::to_string(size) + " != r " + std::to_string(r);
+        return COLBWT_ERR_FORMAT;
+    }
+    if (r == 0 || r > 0xFFFFFFFFull - 1) {
+        err = "header: r = " + std::to_string(r) + " outside [1, 2^32-2] (RUN_BYTES = 4, common.hpp:53)";
+        return COLBWT_ERR_FORMAT;
+    }
+    if (n < r || n >= (1ull << 40)) {
+        err = "header: n = " + std::to_string(n) + " outside [r, 2^40) (BWT_BYTES = 5, common.hpp:52)";
+        return COLBWT_ERR_FORMAT;
+    }
+    if (len != kHeaderBytes + r * (uint64_t)kRowBytesDisk) {
+        err = "file length " + std::to_string(len) + " != 32 + 18*" + std::to_string(r) +
+              " (row widths other than the shipped 5/4/2/8 are not supported)";
+        return COLBWT_ERR_FORMAT;
+    }
+    int rc = select_device(device, err);
+    if (rc != COLBWT_OK) return rc;
+    release();
+    device_ = device;
+    bwt_r_ = bwt_r;
+
+    const uint8_t *rows_disk = bytes + kHeaderBytes;
+    const uint32_t nblk = (uint32_t)((r + (1u << kBlockShift) - 1) >> kBlockShift);
+
+    HIP_TRY(hipMalloc(&d_rows_, (r + 1) * sizeof(uint4)));
+    HIP_TRY(hipMalloc(&d_thr_, r * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&d_cmap_, 256));
+    device_bytes_ = (r + 1) * sizeof(uint4) + r * sizeof(uint64_t) + 256;
+
+    // ---- upload packed rows chunk by chunk and re-lay them out on the device
+    RelayoutReport *d_report = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_report, sizeof(RelayoutReport)));
+    RelayoutReport h_report{};
+    h_report.first_bad = kNone;
+    HIP_TRY(hipMemcpy(d_report, &h_report, sizeof(h_report), hipMemcpyHostToDevice));
+
+    const uint64_t chunk_rows = 16ull << 20;  // 288 MiB of packed rows per staging pass
+    const uint64_t stage_rows = std::min<uint64_t>(chunk_rows, r);
+    uint8_t *d_raw = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_raw, (stage_rows + 1) * kRowBytesDisk + 64));
+    for (uint64_t row0 = 0; row0 < r; row0 += chunk_rows) {
+        const uint64_t count = std::min<uint64_t>(chunk_rows, r - row0);
+        const uint64_t with_next = std::min<uint64_t>(count + 1, r - row0);  // next row's idx for run lengths
+        hipError_t e = hipMemcpy(d_raw, rows_disk + row0 * kRowBytesDisk, with_next * kRowBytesDisk,
+                                 hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_raw);
+            (void)hipFree(d_report);
+            err = std::string("hipMemcpy(rows): ") + hipGetErrorString(e);
+            return COLBWT_ERR_HIP;
+        }
+        launch_relayout(d_raw, row0, count, r, n, (uint4 *)d_rows_, (uint64_t *)d_thr_, d_report, 0);
+        HIP_TRY(hipStreamSynchronize(0));
+    }
+    (void)hipFree(d_raw);
+    HIP_TRY(hipMemcpy(&h_report, d_report, sizeof(h_report), hipMemcpyDeviceToHost));
+    (void)hipFree(d_report);
+    if (h_report.flags) {
+        err = "corrupt .col_pml near row " + std::to_string(h_report.first_bad) + ":";
+        if (h_report.flags & 1u) err += " idx not strictly increasing;";
+        if (h_report.flags & 2u) err += " interval >= r;";
+        if (h_report.flags & 4u) err += " last idx >= n;";
+        if (h_report.flags & 8u) err += " idx[0] != 0;";
+        release();
+        return COLBWT_ERR_FORMAT;
+    }
+
+    // ---- character map: byte -> dense index over the characters present
+    uint8_t cmap[256];
+    uint32_t sigma = 0;
+    for (uint32_t c = 0; c < 256; ++c) {
+        const bool present = (h_report.present[c >> 5] >> (c & 31)) & 1u;
+        cmap[c] = present ? (uint8_t)sigma++ : (uint8_t)kAbsent;
+    }
+    if (sigma > 255) {  // 256 distinct bytes: index 255 would collide with kAbsent
+        err = "all 256 byte values occur in the BWT; not supported";
+        release();
+        return COLBWT_ERR_FORMAT;
+    }
+    HIP_TRY(hipMemcpy(d_cmap_, cmap, 256, hipMemcpyHostToDevice));
+
+    // ---- jump tables bounding succ_char / pred_char (LF_table.hpp:271-298)
+    const uint64_t tbl_entries = (uint64_t)nblk * sigma;
+    HIP_TRY(hipMalloc(&d_next_, std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_prev_, std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
+    device_bytes_ += 2 * std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t);
+    {
+        launch_block_first_last((const uint4 *)d_rows_, (uint32_t)r, nblk, sigma, (const uint8_t *)d_cmap_,
+                                (uint32_t *)d_next_, (uint32_t *)d_prev_, 0);
+        HIP_TRY(hipStreamSynchronize(0));
+        std::vector<uint32_t> first(tbl_entries), last(tbl_entries);
+        HIP_TRY(hipMemcpy(first.data(), d_next_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(last.data(), d_prev_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        // next[b][c] = first run >= b*B holding c ; prev[b][c] = last run < b*B holding c
+        std::vector<uint32_t> next(tbl_entries), prev(tbl_entries);
+        for (uint32_t c = 0; c < sigma; ++c) {
+            uint32_t carry = kNone;
+            for (uint64_t b = nblk; b-- > 0;) {
+                const uint32_t f = first[b * sigma + c];
+                if (f != kNone) carry = f;
+                next[b * sigma + c] = carry;
+            }
+            carry = kNone;
+            for (uint64_t b = 0; b < nblk; ++b) {
+                prev[b * sigma + c] = carry;
+                const uint32_t l = last[b * sigma + c];
+                if (l != kNone) carry = l;
+            }
+        }
+        HIP_TRY(hipMemcpy(d_next_, next.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_prev_, prev.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+
+    tbl_.rows = (const uint4 *)d_rows_;
+    tbl_.thr = (const uint64_t *)d_thr_;
+    tbl_.next_tbl = (const uint32_t *)d_next_;
+    tbl_.prev_tbl = (const uint32_t *)d_prev_;
+    tbl_.cmap = (const uint8_t *)d_cmap_;
+    tbl_.n = n;
+    tbl_.r = (uint32_t)r;
+    tbl_.sigma = sigma;
+    tbl_.nblk = nblk;
+    return COLBWT_OK;
+}
+
+}  // namespace colbwt

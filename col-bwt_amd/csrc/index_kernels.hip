@@ -1,0 +1,203 @@
+// index_kernels.hip -- load-time kernels: on-disk rows -> HBM layout, jump
+// tables, and the synthetic read sampler.  None of this is on the query path;
+// it runs once per index (col_pml::load, col_bwt.hpp:375-380).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+#include "query_kernels.h"
+
+namespace colbwt {
+
+namespace {
+
+constexpr uint32_t kRelayoutBlock = 256;
+constexpr uint32_t kStageBytes = kRelayoutBlock * kRowBytesDisk + 24;  // block's rows + next row's idx, dword padded
+
+__device__ __forceinline__ uint64_t lds_le(const uint8_t *p, uint32_t nbytes) {
+    uint64_t v = 0;
+    for (uint32_t b = 0; b < nbytes; ++b) v |= (uint64_t)p[b] << (8 * b);
+    return v;
+}
+
+// One thread per row.  The block's packed rows are staged in LDS with
+// coalesced dword loads (18-byte rows are only byte aligned), then decoded:
+//   byte 0 char | 1-5 idx | 6-9 interval | 10-11 offset | 12 col_id | 13-17 threshold
+// (memory image of col_thr: LF_table.hpp:33-40, col_bwt.hpp:43,84).
+__global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t *__restrict__ raw, uint64_t row0,
+                                                                  uint64_t count, uint64_t r, uint64_t n,
+                                                                  uint4 *__restrict__ rows, uint64_t *__restrict__ thr,
+                                                                  RelayoutReport *report) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
+    __shared__ uint32_t s_present[8];
+    __shared__ uint32_t s_flags, s_bad;
+    const uint64_t blk_row = (uint64_t)blockIdx.x * kRelayoutBlock;  // relative to row0
+    if (threadIdx.x < 8) s_present[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_flags = 0; s_bad = kNone; }
+
+    const uint64_t rows_here = (count - blk_row) < kRelayoutBlock ? (count - blk_row) : kRelayoutBlock;
+    // bytes of this block's rows, plus 6 bytes (char + idx) of the following row when it exists
+    const bool has_next = (row0 + blk_row + rows_here) < r;
+    const uint32_t need = (uint32_t)rows_here * kRowBytesDisk + (has_next ? 6u : 0u);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(raw + blk_row * kRowBytesDisk);  // 4608*k: dword aligned
+    uint32_t *dst = reinterpret_cast<uint32_t *>(stage);
+    for (uint32_t d = threadIdx.x; d * 4 < need; d += kRelayoutBlock) dst[d] = src[d];
+    __syncthreads();
+
+    if (threadIdx.x < rows_here) {
+        const uint64_t i = row0 + blk_row + threadIdx.x;
+        const uint8_t *p = stage + threadIdx.x * kRowBytesDisk;
+        const uint32_t ch = p[0];
+        const uint64_t idx = lds_le(p + 1, 5);
+        const uint32_t interval = (uint32_t)lds_le(p + 6, 4);
+        const uint32_t offset = (uint32_t)lds_le(p + 10, 2);
+        const uint32_t cid = p[12];
+        const uint64_t threshold = lds_le(p + 13, 5);
+        const uint64_t next_idx = (i + 1 < r) ? lds_le(p + kRowBytesDisk + 1, 5) : n;
+
+        uint32_t flags = 0;
+        if (next_idx <= idx) flags |= (i + 1 < r) ? 1u : 4u;  // not strictly increasing / last idx >= n
+        if ((uint64_t)interval >= r) flags |= 2u;
+        if (i == 0 && idx != 0) flags |= 8u;
+        if (flags) {
+            atomicOr(&s_flags, flags);
+            atomicMin(&s_bad, (uint32_t)i);
+        }
+        const uint64_t len = next_idx - idx;
+        const uint32_t len16 = len < kLenLong ? (uint32_t)len : kLenLong;
+        rows[i] = make_uint4(interval, offset | (len16 << 16), (uint32_t)idx,
+                             (uint32_t)(idx >> 32) | (ch << 8) | (cid << 16));
+        thr[i] = threshold;
+        if (i + 1 == r) rows[r] = make_uint4(0, 0, (uint32_t)n, (uint32_t)(n >> 32));  // sentinel: idx = n
+        atomicOr(&s_present[ch >> 5], 1u << (ch & 31));
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && s_present[threadIdx.x]) atomicOr(&report->present[threadIdx.x], s_present[threadIdx.x]);
+    if (threadIdx.x == 0 && s_flags) {
+        atomicOr(&report->flags, s_flags);
+        atomicMin(&report->first_bad, s_bad);
+    }
+}
+
+// One wave per 256-row jump block: first / last row of the block holding each
+// present character (kNone when the block has none).
+__global__ __launch_bounds__(256) void block_first_last_kernel(const uint4 *__restrict__ rows, uint32_t r,
+                                                               uint32_t nblk, uint32_t sigma,
+                                                               const uint8_t *__restrict__ cmap,
+                                                               uint32_t *__restrict__ first,
+                                                               uint32_t *__restrict__ last) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const uint64_t base = (uint64_t)b << kBlockShift;
+    uint32_t cx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint64_t row = base + (uint64_t)s * 64 + lane;
+        cx[s] = kNone;
+        if (row < r) cx[s] = cmap[(rows[row].w >> 8) & 0xFFu];
+    }
+    for (uint32_t c = 0; c < sigma; ++c) {
+        uint32_t f = kNone, l = kNone;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned long long m = __ballot(cx[s] == c);
+            if (m) {
+                const uint32_t lo = (uint32_t)base + s * 64 + (uint32_t)__builtin_ctzll(m);
+                const uint32_t hi = (uint32_t)base + s * 64 + 63u - (uint32_t)__builtin_clzll(m);
+                if (f == kNone) f = lo;
+                l = hi;
+            }
+        }
+        if (lane == 0) {
+            first[(uint64_t)b * sigma + c] = f;
+            last[(uint64_t)b * sigma + c] = l;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint64_t d_row_idx(const uint4 &w) {
+    return (uint64_t)w.z | ((uint64_t)(w.w & 0xFFu) << 32);
+}
+
+// Synthetic reads by backward walk: read[m-1-k] = char at
+// LF^k(p0).  Generator only -- results are inputs, never checked outputs.
+__global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n_reads, uint32_t m,
+                                                          uint32_t sub_permille, uint64_t seed,
+                                                          uint8_t *__restrict__ bases,
+                                                          uint64_t *__restrict__ read_off) {
+    const uint64_t rd = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (rd > n_reads) return;
+    read_off[rd] = rd * m;
+    if (rd == n_reads) return;
+    uint64_t st = splitmix64(seed ^ (rd * 0xD1342543DE82EF95ull));
+    const uint64_t p0 = st % T.n;
+    // largest i with idx[i] <= p0
+    uint64_t lo = 0, hi = T.r;  // idx[lo] <= p0 < idx[hi] (sentinel idx[r] = n)
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (d_row_idx(T.rows[mid]) <= p0) lo = mid; else hi = mid;
+    }
+    uint32_t i = (uint32_t)lo;
+    uint4 w = T.rows[i];
+    uint64_t o = p0 - d_row_idx(w);
+    uint8_t *out = bases + rd * m;
+    const char acgt[4] = {'A', 'C', 'G', 'T'};
+    for (uint32_t k = 0; k < m; ++k) {
+        uint32_t ch = (w.w >> 8) & 0xFFu;
+        if (ch <= 1) ch = 'A';
+        st = splitmix64(st);
+        if ((uint32_t)(st % 1000) < sub_permille) {
+            uint32_t cur = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+            uint32_t pick = (uint32_t)((st >> 32) % 3);
+            ch = cur < 4 ? acgt[(cur + 1 + pick) & 3] : acgt[(st >> 40) & 3];
+        }
+        out[m - 1 - k] = (uint8_t)ch;
+        uint32_t j = w.x;
+        uint64_t t = (uint64_t)(w.y & 0xFFFFu) + o;
+        w = T.rows[j];
+        for (;;) {
+            const uint64_t len = d_row_idx(T.rows[(uint64_t)j + 1]) - d_row_idx(w);
+            if (t < len || j >= T.r - 1) break;
+            t -= len;
+            ++j;
+            w = T.rows[j];
+        }
+        i = j;
+        o = t;
+    }
+    (void)i;
+}
+
+}  // namespace
+
+void launch_relayout(const uint8_t *d_raw, uint64_t row0, uint64_t count, uint64_t r, uint64_t n, uint4 *d_rows,
+                     uint64_t *d_thr, RelayoutReport *d_report, hipStream_t stream) {
+    if (count == 0) return;
+    const uint32_t blocks = (uint32_t)((count + kRelayoutBlock - 1) / kRelayoutBlock);
+    hipLaunchKernelGGL(relayout_kernel, dim3(blocks), dim3(kRelayoutBlock), 0, stream, d_raw, row0, count, r, n,
+                       d_rows, d_thr, d_report);
+}
+
+void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uint32_t sigma, const uint8_t *d_cmap,
+                             uint32_t *d_first, uint32_t *d_last, hipStream_t stream) {
+    if (nblk == 0) return;
+    hipLaunchKernelGGL(block_first_last_kernel, dim3((nblk + 3) / 4), dim3(256), 0, stream, d_rows, r, nblk, sigma,
+                       d_cmap, d_first, d_last);
+}
+
+void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille, uint64_t seed,
+                        uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream) {
+    const uint64_t blocks = (n_reads + 1 + 255) / 256;
+    hipLaunchKernelGGL(synth_reads_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, T, n_reads, read_len,
+                       sub_permille, seed, d_bases, d_read_off);
+}
+
+}  // namespace colbwt

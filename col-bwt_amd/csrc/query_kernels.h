@@ -1,0 +1,34 @@
+// query_kernels.h -- host-visible launchers of the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+namespace colbwt {
+
+constexpr uint32_t kQueryBlock = 256;  // 4 waves; one lane per read
+
+// col_pml::query_pml for n_reads reads resident in HBM (col_bwt.hpp:498-529).
+void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t *d_read_off,
+                      uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream);
+
+// ---- load-time kernels (index_kernels.hip) --------------------------------
+struct RelayoutReport {
+    uint32_t flags;      // bit0 idx not strictly increasing, bit1 interval >= r, bit2 idx >= n, bit3 idx[0] != 0
+    uint32_t first_bad;  // smallest offending row
+    uint32_t present[8]; // 256-bit set of characters seen
+};
+
+// Packed 18-byte rows [row0, row0+count) (plus the following row's idx when it
+// exists) -> 16-byte rows + thresholds; validates as it goes.
+void launch_relayout(const uint8_t *d_raw, uint64_t row0, uint64_t count, uint64_t r, uint64_t n,
+                     uint4 *d_rows, uint64_t *d_thr, RelayoutReport *d_report, hipStream_t stream);
+void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uint32_t sigma,
+                             const uint8_t *d_cmap, uint32_t *d_first, uint32_t *d_last, hipStream_t stream);
+
+// Backward-walk read sampler (synthetic benchmark input).
+void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
+                        uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);
+
+}  // namespace colbwt

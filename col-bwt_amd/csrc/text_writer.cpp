@@ -1,0 +1,75 @@
+// text_writer.cpp -- see text_writer.h (pml_query.cpp:78-85).
+#include "text_writer.h"
+
+#include <string.h>
+
+namespace colbwt {
+
+namespace {
+constexpr size_t kBufBytes = 4u << 20;
+
+// decimal digits of v followed by one space; returns bytes written (<= 11)
+inline size_t put_value(char *dst, uint32_t v) {
+    char tmp[10];
+    int nd = 0;
+    do {
+        tmp[nd++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    for (int d = 0; d < nd; ++d) dst[d] = tmp[nd - 1 - d];
+    dst[nd] = ' ';
+    return (size_t)nd + 1;
+}
+}  // namespace
+
+bool TextWriter::open(const std::string &path) {
+    f_ = fopen(path.c_str(), "wb");  // pml_query.cpp:67,70: std::ofstream, truncating
+    buf_.resize(kBufBytes + 64);
+    used_ = 0;
+    ok_ = f_ != nullptr;
+    return ok_;
+}
+
+bool TextWriter::flush_() {
+    if (used_ && f_) ok_ = ok_ && fwrite(buf_.data(), 1, used_, f_) == used_;
+    used_ = 0;
+    return ok_;
+}
+
+template <typename T>
+bool TextWriter::record(const std::string &name, const T *vals, uint64_t m) {
+    if (!f_) return false;
+    if (used_ + name.size() + 3 > kBufBytes) flush_();
+    if (name.size() + 3 > kBufBytes) {  // absurdly long name: write through
+        flush_();
+        ok_ = ok_ && fputc('>', f_) != EOF && fwrite(name.data(), 1, name.size(), f_) == name.size() &&
+              fwrite(" \n", 1, 2, f_) == 2;
+    } else {
+        buf_[used_++] = '>';
+        memcpy(&buf_[used_], name.data(), name.size());
+        used_ += name.size();
+        buf_[used_++] = ' ';
+        buf_[used_++] = '\n';
+    }
+    for (uint64_t k = 0; k < m; ++k) {
+        if (used_ + 12 > kBufBytes) flush_();
+        used_ += put_value(&buf_[used_], (uint32_t)vals[k]);
+    }
+    if (used_ + 1 > kBufBytes) flush_();
+    buf_[used_++] = '\n';
+    return ok_;
+}
+
+template bool TextWriter::record<uint8_t>(const std::string &, const uint8_t *, uint64_t);
+template bool TextWriter::record<uint16_t>(const std::string &, const uint16_t *, uint64_t);
+template bool TextWriter::record<uint32_t>(const std::string &, const uint32_t *, uint64_t);
+
+bool TextWriter::close() {
+    if (!f_) return ok_;
+    flush_();
+    ok_ = (fclose(f_) == 0) && ok_;
+    f_ = nullptr;
+    return ok_;
+}
+
+}  // namespace colbwt

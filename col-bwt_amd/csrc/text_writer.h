@@ -1,0 +1,34 @@
+// text_writer.h -- the reference's text output (pml_to_vec, pml_query.cpp:65-90):
+// per read  '>' name ' ' '\n'  then every value followed by one space, then
+// '\n'; k-th value <-> pattern[k].  Byte-identical to
+//   fs << '>' << id << " \n"; std::copy(v.begin(), v.end(), std::ostream_iterator<size_t>(fs, " ")); fs << "\n";
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+namespace colbwt {
+
+class TextWriter {
+public:
+    TextWriter() = default;
+    ~TextWriter() { close(); }
+    TextWriter(const TextWriter &) = delete;
+    TextWriter &operator=(const TextWriter &) = delete;
+
+    bool open(const std::string &path);
+    template <typename T>
+    bool record(const std::string &name, const T *vals, uint64_t m);
+    bool close();
+
+private:
+    bool flush_();
+    FILE *f_ = nullptr;
+    std::vector<char> buf_;
+    size_t used_ = 0;
+    bool ok_ = true;
+};
+
+}  // namespace colbwt

@@ -1,0 +1,143 @@
+/*
+ * colbwt.h -- C-ABI of the MI355X-native col-bwt PML / chain-statistic query
+ * engine (libcolbwt.so, hand-written HIP for gfx950).
+ *
+ * The reference (drnatebrown/col-bwt) has no FFI layer; the entry points below
+ * are the ones a binding of its query path would need.  Each cites the
+ * reference interface (file:line under /root/reference) it replaces.
+ *
+ *   col_pml tbl; tbl.load(ifstream)            col_bwt.hpp:375-380, LF_table.hpp:347-357
+ *        -> colbwt_index_open / colbwt_index_open_memory
+ *   tbl.query_pml(const char*, size_t)         col_bwt.hpp:409-412 (one read)
+ *        -> colbwt_query_batch (many reads per call; read k of the batch is
+ *           what one query_pml call returns: pml[k'], cid[k'] <-> pattern[k'])
+ *   pml_to_vec / main of pml_query             pml_query.cpp:65-90, 92-143
+ *        -> colbwt_query_file (FASTA/FASTQ[.gz] in, text .pml/.cid out)
+ *   ~col_pml                                   (implicit)
+ *        -> colbwt_index_close
+ *
+ * Conventions: plain pointers and sizes, caller-owned buffers, int return
+ * codes (0 = ok, <0 = error; message via colbwt_last_error(), thread-local),
+ * no exceptions cross the ABI.  An index may be queried from several host
+ * threads at once on distinct batches (each call uses its own stream).
+ * There is NO CPU fallback: every query entry point fails with
+ * COLBWT_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef COLBWT_H
+#define COLBWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLBWT_OK 0
+#define COLBWT_ERR_ARG (-1)        /* bad argument (null, misaligned, sizes)  */
+#define COLBWT_ERR_IO (-2)         /* file missing / short read               */
+#define COLBWT_ERR_FORMAT (-3)     /* .col_pml fails validation               */
+#define COLBWT_ERR_NO_DEVICE (-4)  /* no usable HIP device                    */
+#define COLBWT_ERR_HIP (-5)        /* a HIP call failed                       */
+#define COLBWT_ERR_NOMEM (-6)
+
+typedef struct colbwt_index colbwt_index; /* opaque: table resident in HBM */
+
+/* On-disk widths of the reference build (common.hpp:46-54).  Only the shipped
+ * values are accepted; the struct exists so a binding can assert them. */
+typedef struct colbwt_widths {
+    uint32_t bwt_bytes; /* BWT_BYTES 5 */
+    uint32_t run_bytes; /* RUN_BYTES 4 */
+    uint32_t len_bytes; /* LEN_BYTES 2 */
+    uint32_t id_bits;   /* ID_BITS   8 */
+} colbwt_widths;
+
+typedef struct colbwt_info {
+    uint64_t bwt_r;        /* maximal BWT runs      (col_bwt.hpp:383)  */
+    uint64_t n;            /* BWT length            (LF_table.hpp:360) */
+    uint64_t r;            /* rows (sub-runs)       (LF_table.hpp:361) */
+    uint32_t sigma;        /* distinct characters present in the table */
+    uint32_t device;       /* HIP device ordinal                       */
+    uint64_t device_bytes; /* HBM held by the index                    */
+} colbwt_info;
+
+typedef struct colbwt_stats {
+    uint64_t n_reads;
+    uint64_t n_bases;
+    double h2d_ms;     /* reads host->HBM (0 for the device entry point)    */
+    double kernel_ms;  /* HIP-event time of the query kernel(s), on-stream  */
+    double d2h_ms;     /* results HBM->host (0 for the device entry point)  */
+    uint64_t algorithmic_bytes; /* 27 B/base, SURVEY.md section 8(d)         */
+} colbwt_stats;
+
+const char *colbwt_version(void);
+const char *colbwt_last_error(void);
+
+/* col_pml::load (col_bwt.hpp:375-380).  `prefix_or_file`: either the index
+ * prefix (".col_pml" is appended, pml_query.cpp:110-111; extension from
+ * col_bwt.hpp:434-437) or the path of the .col_pml file itself.  `widths` may
+ * be NULL (shipped widths).  Unlike the reference (UB on a bad file) the
+ * loader validates: size == r, file length == 32 + 18*size, idx strictly
+ * increasing from 0 and < n, interval < r. */
+int colbwt_index_open(const char *prefix_or_file, const colbwt_widths *widths, int device,
+                      colbwt_index **out);
+/* Same over an in-memory image of the .col_pml file. */
+int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,
+                             int device, colbwt_index **out);
+void colbwt_index_close(colbwt_index *idx);
+int colbwt_index_info(const colbwt_index *idx, colbwt_info *out);
+
+/* col_pml::query_pml for a batch of reads held in HOST memory
+ * (col_bwt.hpp:409-412 -> :460-472 -> :498-529).  Read k is
+ * bases[read_off[k] .. read_off[k+1]); read_off has n_reads+1 entries,
+ * read_off[0] == 0.  Outputs are indexed like `bases`.  PML is u16; a batch
+ * containing a read longer than 65535 must use the _u32 form (ERR_ARG
+ * otherwise).  `stats` may be NULL. */
+int colbwt_query_batch(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off,
+                       uint64_t n_reads, uint16_t *pml, uint8_t *cid, colbwt_stats *stats);
+int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off,
+                           uint64_t n_reads, uint32_t *pml, uint8_t *cid, colbwt_stats *stats);
+
+/* Same computation with every buffer already resident in HBM on the index's
+ * device (the benchmark / multi-GPU path).  Requirements: d_bases has at least
+ * 16 readable bytes past read_off[n_reads]; d_bases and d_pml are 16-byte
+ * aligned, d_cid 8-byte aligned; pml_bytes is 2 or 4.  `hip_stream` is a
+ * hipStream_t (NULL = default stream); the call is asynchronous unless
+ * `stats` is non-NULL, in which case it records HIP events on the stream,
+ * synchronises it and fills kernel_ms. */
+int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off,
+                        uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes,
+                        uint8_t *d_cid, void *hip_stream, colbwt_stats *stats);
+
+/* pml_query in vec mode (pml_query.cpp:92-143): reads FASTA/FASTQ (optionally
+ * gzip) from pattern_path, writes text pml_path / cid_path (NULL => pattern +
+ * ".pml" / ".cid", pml_query.cpp:124-125) in the byte format of pml_to_vec
+ * (pml_query.cpp:78-85).  `batch_bases` bounds the bases per GPU batch
+ * (0 = default). */
+int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path,
+                      const char *cid_path, uint64_t batch_bases, colbwt_stats *stats);
+
+/* ---- synthetic inputs (benchmark / test generators) ------ */
+
+/* Bytes needed for a synthetic .col_pml image of `rows` rows. */
+uint64_t colbwt_synth_index_bytes(uint64_t rows);
+/* Direct move-table synthesis: adjacent-distinct ACGT heads (+ one 0x01 run of
+ * length 1 at row rows/2), Geometric(mean_len) lengths, (interval, offset)
+ * from the stable char-sorted F order, col ids from {0,0,0,1,2,3,17,200,255},
+ * thresholds uniform in [0,n).  `split_permille`: per-mille probability that a
+ * row repeats the previous row's character (a sub-run split; 0 => bwt_r == r).
+ * Writes the file image into `out` (colbwt_synth_index_bytes(rows) bytes). */
+int colbwt_synth_index(uint64_t rows, uint32_t mean_len, uint32_t split_permille, uint64_t seed,
+                       void *out, uint64_t out_len);
+/* Backward-walk reads sampled ON THE DEVICE from the loaded index:
+ * read[m-1-k] = char at LF^k(p0), p0 uniform; 0x01 -> 'A'; substitutions at
+ * `sub_permille`/1000.  Writes n_reads*read_len bytes (+16 pad bytes zeroed)
+ * to d_bases and n_reads+1 offsets to d_read_off (both device pointers). */
+int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len,
+                              uint32_t sub_permille, uint64_t seed, uint8_t *d_bases,
+                              uint64_t *d_read_off, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLBWT_H */

@@ -1,0 +1,119 @@
+// tests/emu/hip/hip_runtime.h -- a tiny SIMT *emulator* of the HIP vocabulary
+// the product sources use, so that the very same .hip files can be compiled
+// with g++ and exercised on a CPU-only box (with ASan/UBSan) by the
+// `-m "not gpu"` test tier.
+//
+// TEST INFRASTRUCTURE ONLY.  It is never built by __graft_entry__.build(),
+// never linked into libcolbwt.so and never shipped: the product has no host
+// path.  One OS thread per GPU thread of a block, blocks run one after the
+// other; __syncthreads / __ballot are real rendezvous among those threads.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+struct dim3 {
+    uint32_t x, y, z;
+    dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+typedef struct emu_stream *hipStream_t;
+typedef struct emu_event { double t; } *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1 };
+
+namespace emu {
+struct Barrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t expected = 0, arrived = 0, generation = 0;
+    uint64_t ballot_acc = 0, ballot_out = 0;
+    void reset(uint32_t n) { expected = n; arrived = 0; generation = 0; ballot_acc = 0; }
+    // returns the OR of `bits` over all participants of this generation
+    uint64_t arrive(uint64_t bits) {
+        std::unique_lock<std::mutex> lk(mu);
+        ballot_acc |= bits;
+        if (++arrived >= expected) {
+            ballot_out = ballot_acc; ballot_acc = 0; arrived = 0; ++generation;
+            cv.notify_all();
+            return ballot_out;
+        }
+        const uint32_t gen = generation;
+        cv.wait(lk, [&] { return generation != gen; });
+        return ballot_out;
+    }
+    void leave() {  // a thread returned from the kernel: stop waiting for it
+        std::unique_lock<std::mutex> lk(mu);
+        if (expected) --expected;
+        if (expected && arrived >= expected) {
+            ballot_out = ballot_acc; ballot_acc = 0; arrived = 0; ++generation;
+            cv.notify_all();
+        }
+    }
+};
+struct Ctx { dim3 tid, bid, bdim, gdim; Barrier *block; Barrier *wave; };
+extern thread_local Ctx ctx;
+extern std::mutex atomic_mu;
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+double now_ms();
+}  // namespace emu
+
+#define threadIdx (emu::ctx.tid)
+#define blockIdx (emu::ctx.bid)
+#define blockDim (emu::ctx.bdim)
+#define gridDim (emu::ctx.gdim)
+
+static inline void __syncthreads() { emu::ctx.block->arrive(0); }
+static inline unsigned long long __ballot(int pred) {
+    return emu::ctx.wave->arrive(pred ? (1ull << (emu::ctx.tid.x & 63)) : 0ull);
+}
+static inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o | v; return o;
+}
+static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; if (v < o) *p = v; return o;
+}
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+static inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) {
+    // exact-size allocations so ASan sees every out-of-bounds device access
+    *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::now_ms(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""CPU-tier parity of the product's HIP sources compiled against the SIMT
+emulator (tests/emu/hip/hip_runtime.h) vs the oracle.  Run by
+tests/test_emu_parity.py in a subprocess with libasan preloaded, so every
+out-of-bounds access of the kernels / host logic is fatal.
+
+This is a test instrument: the shipped libcolbwt.so has no host path.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+import helpers  # noqa: E402
+
+pkg = load_package()
+pkg.LIB_PATH = os.path.join(HERE, "libcolbwt_emu.so")   # emulated build instead of the HIP one
+oracle = load_oracle()
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def check(image, reads, label, wide=False):
+    image = bytes(image)
+    bases, off = helpers.concat_reads(reads)
+    tbl = pkg.ColPml.from_bytes(image)
+    ref = oracle.OracleIndex(image)
+    pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
+    epml, ecid = ref.query_batch(bases, off, wide=wide)
+    assert np.array_equal(pml, epml), f"{label}: PML differs at {np.flatnonzero(pml != epml)[:5]}"
+    assert np.array_equal(cid, ecid), f"{label}: CID differs at {np.flatnonzero(cid != ecid)[:5]}"
+    tbl.close()
+    print(f"ok {label}: {len(reads)} reads, {int(off[-1])} bases")
+
+
+def rand_reads(rng, n, lo, hi, alphabet=b"ACGT"):
+    return [rng.choice(np.frombuffer(alphabet, np.uint8), size=int(m)) for m in rng.integers(lo, hi + 1, size=n)]
+
+
+def main():
+    rng = np.random.default_rng(11)
+
+    # 1. golden KAT
+    img = open(os.path.join(GOLD, "kat_d.col_pml"), "rb").read()
+    kat = [np.frombuffer(s, np.uint8) for s in (b"GATTACA", b"TTACCGATNACA", b"CCCC")]
+    check(img, kat, "kat_d")
+    tbl = pkg.ColPml.from_bytes(img)
+    exp = {b"GATTACA": ([5, 4, 3, 2, 1, 0, 1], [1, 3, 1, 3, 3, 1, 3]),
+           b"CCCC": ([0, 0, 1, 0], [3, 3, 0, 3])}
+    for s, (p, c) in exp.items():
+        gp, gc = tbl.query_pml(s)
+        assert gp.tolist() == p and gc.tolist() == c
+    # text path: FASTA in, .pml/.cid out, byte-identical to the reference's files
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "kat_d.fa")
+        open(fa, "wb").write(open(os.path.join(GOLD, "kat_d.fa"), "rb").read())
+        tbl.query_file(fa)
+        for ext in (".pml", ".cid"):
+            assert open(fa + ext, "rb").read() == open(os.path.join(GOLD, "kat_d.fa" + ext), "rb").read(), ext
+    tbl.close()
+    print("ok kat_d text")
+
+    # 2. true BWT index, reads with substitutions, N and lowercase (no case folding)
+    seqs = []
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300)
+    for _ in range(4):
+        s = base.copy()
+        mut = rng.random(300) < 0.03
+        s[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(mut.sum()))
+        seqs.append(bytes(s))
+    img, text = helpers.true_bwt_index(seqs, seed=5, extra_splits=40)
+    reads = helpers.reads_from_text(text, 60, (1, 120), 0.05, seed=6, extra=b"Nacgt")
+    reads += [np.zeros(0, np.uint8), np.frombuffer(b"A", np.uint8)]       # empty + 1-base reads
+    reads += rand_reads(rng, 20, 1, 40)
+    check(img, reads, "true_bwt")
+
+    # 3. synthetic tables spanning several jump blocks; sub-run splits
+    for rows, split, seed in ((700, 0, 1), (3000, 150, 2), (257, 300, 3), (256, 0, 4)):
+        img = pkg.synth_index(rows, mean_len=6, split_permille=split, seed=seed)
+        reads = helpers.backward_walk_reads(img, 40, 70, 0.02, seed=seed)
+        reads += rand_reads(rng, 40, 0, 90)
+        reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
+        check(img, reads, f"synth_{rows}_{split}")
+
+    # 4. rare character far away: scans must leave the block and use the jump tables
+    r = 2000
+    chars = np.tile(np.frombuffer(b"AC", np.uint8), r // 2)
+    chars[3] = ord("G"); chars[1500] = ord("G"); chars[900] = 1
+    lens = rng.integers(1, 9, size=r)
+    idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    n = int(lens.sum())
+    interval, offset = helpers.lf_columns(chars, idx, n)
+    thr = rng.integers(0, n, size=r)
+    cid = rng.integers(0, 256, size=r)
+    img = helpers.pack_col_pml(r, n, chars, idx, interval, offset, cid, thr)
+    reads = rand_reads(rng, 60, 1, 60, alphabet=b"ACGGG\x01T")
+    check(img, reads, "rare_char")
+
+    # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
+    r = 600
+    chars = np.tile(np.frombuffer(b"ACGT", np.uint8), r // 4)
+    lens = rng.integers(1, 50, size=r)
+    lens[[5, 77, 300, r - 1]] = [65535, 70000, 200000, 66000]
+    idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    n = int(lens.sum())
+    interval, offset = helpers.lf_columns(chars, idx, n)
+    offset = offset & np.uint64(0xFFFF)            # what the 16-bit field keeps (LF_table.hpp:39)
+    thr = rng.integers(0, n, size=r)
+    img = helpers.pack_col_pml(r, n, chars, idx, interval, offset, rng.integers(0, 256, size=r), thr)
+    check(img, rand_reads(rng, 50, 1, 80), "long_runs")
+
+    # 6. u32 PML: a read longer than 65535 bases
+    img = pkg.synth_index(500, mean_len=4, split_permille=0, seed=9)
+    long_read = helpers.backward_walk_reads(img, 1, 66000, 0.0005, seed=10)
+    check(img, long_read + rand_reads(rng, 3, 1, 30), "wide_pml", wide=True)
+    try:
+        bases, off = helpers.concat_reads(long_read)
+        pkg.ColPml.from_bytes(bytes(img)).query_batch(bases, off, wide=False)
+        raise SystemExit("u16 call with a 66000-base read must fail")
+    except pkg.ColbwtError as e:
+        assert e.code == -1
+
+    # 7. loader validation (the reference has none: UB on a bad file)
+    good = bytearray(pkg.synth_index(300, mean_len=5, seed=12).tobytes())
+    for label, mutate in (
+            ("short", lambda b: b[:-1]),
+            ("size!=r", lambda b: b[:24] + (299).to_bytes(8, "little") + b[32:]),
+            ("interval>=r", lambda b: b[:32 + 18 * 10 + 6] + (10**6).to_bytes(4, "little") + b[32 + 18 * 10 + 10:]),
+            ("idx order", lambda b: b[:32 + 18 * 20 + 1] + (0).to_bytes(5, "little") + b[32 + 18 * 20 + 6:])):
+        bad = bytes(mutate(bytes(good)))
+        try:
+            pkg.ColPml.from_bytes(bad)
+            raise SystemExit(f"loader accepted a corrupt image ({label})")
+        except pkg.ColbwtError as e:
+            assert e.code == -3, (label, e)
+    print("ok loader validation")
+    print("EMU-ALL-OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+"""Test input builders (numpy): `.col_pml` images and reads.
+
+Format: SURVEY.md Appendix A (col_bwt.hpp:360-370, LF_table.hpp:325-342).
+These are INPUT generators; expected outputs always come from the oracle
+(oracle/) or the committed golden vectors (tests/golden/).
+"""
+import struct
+
+import numpy as np
+
+ROW = 18
+HDR = 32
+
+
+def pack_col_pml(bwt_r, n, chars, idx, interval, offset, cid, thr):
+    """Raw memory image of vector<col_thr> behind the 4xu64 header."""
+    r = len(chars)
+    rows = np.zeros((r, ROW), np.uint8)
+    rows[:, 0] = np.asarray(chars, np.uint8)
+    idx = np.asarray(idx, np.uint64)
+    thr = np.asarray(thr, np.uint64)
+    interval = np.asarray(interval, np.uint64)
+    offset = np.asarray(offset, np.uint64)
+    for b in range(5):
+        rows[:, 1 + b] = (idx >> np.uint64(8 * b)) & np.uint64(0xFF)
+        rows[:, 13 + b] = (thr >> np.uint64(8 * b)) & np.uint64(0xFF)
+    for b in range(4):
+        rows[:, 6 + b] = (interval >> np.uint64(8 * b)) & np.uint64(0xFF)
+    for b in range(2):
+        rows[:, 10 + b] = (offset >> np.uint64(8 * b)) & np.uint64(0xFF)
+    rows[:, 12] = np.asarray(cid, np.uint8)
+    return struct.pack("<4Q", bwt_r, n, r, r) + rows.tobytes()
+
+
+def unpack_col_pml(image):
+    """-> dict of numpy arrays (char, idx, interval, offset, cid, thr) + header."""
+    image = bytes(image)
+    bwt_r, n, r, size = struct.unpack_from("<4Q", image, 0)
+    rows = np.frombuffer(image, np.uint8, size * ROW, HDR).reshape(size, ROW).astype(np.uint64)
+
+    def le(lo, nb):
+        v = np.zeros(size, np.uint64)
+        for b in range(nb):
+            v |= rows[:, lo + b] << np.uint64(8 * b)
+        return v
+    return dict(bwt_r=bwt_r, n=n, r=r, char=rows[:, 0].astype(np.uint8), idx=le(1, 5), interval=le(6, 4),
+                offset=le(10, 2), cid=rows[:, 12].astype(np.uint8), thr=le(13, 5))
+
+
+def lf_columns(chars, idx, n):
+    """(interval, offset) of every row: LF_table::compute_table (LF_table.hpp:365-387):
+    rows sorted stably by character tile F; a row's F start lands in row
+    `interval` at `offset`."""
+    chars = np.asarray(chars, np.uint8)
+    idx = np.asarray(idx, np.int64)
+    r = len(chars)
+    lens = np.diff(np.append(idx, n))
+    order = np.argsort(chars, kind="stable")
+    fstart = np.zeros(r, np.int64)
+    fstart[order] = np.concatenate(([0], np.cumsum(lens[order])[:-1]))
+    interval = np.searchsorted(idx, fstart, side="right") - 1
+    offset = fstart - idx[interval]
+    return interval.astype(np.uint64), offset.astype(np.uint64)
+
+
+def true_bwt_index(seqs, seed=0, extra_splits=20, ids=(0, 0, 0, 1, 2, 3, 17, 200, 255), term=1):
+    """A real BWT index of concat(seqs)+terminator: suffix array by sorting,
+    run heads, thresholds = min-LCP position between consecutive same-char
+    runs (0 for the first run of a character), random sub-run splits and ids.
+    Returns (image_bytes, text_bytes)."""
+    rng = np.random.default_rng(seed)
+    text = b"".join(seqs) + bytes([term])
+    n = len(text)
+    sa = sorted(range(n), key=lambda i: text[i:])
+    bwt = np.frombuffer(bytes(text[i - 1] for i in sa), np.uint8)
+    lcp = np.zeros(n, np.int64)
+    for k in range(1, n):
+        a, b = text[sa[k - 1]:], text[sa[k]:]
+        l = 0
+        while l < len(a) and l < len(b) and a[l] == b[l]:
+            l += 1
+        lcp[k] = l
+    heads = np.flatnonzero(np.concatenate(([True], bwt[1:] != bwt[:-1])))
+    bwt_r = len(heads)
+    run_thr = np.zeros(bwt_r, np.int64)
+    last_end = {}
+    for k, h in enumerate(heads):
+        c = int(bwt[h])
+        if c in last_end:
+            lo = last_end[c] + 1           # first position after the previous c-run
+            seg = lcp[lo:h + 1]
+            run_thr[k] = lo + int(np.argmin(seg))
+        end = heads[k + 1] - 1 if k + 1 < bwt_r else n - 1
+        last_end[c] = end
+    split = set(heads.tolist())
+    cand = [p for p in range(n) if p not in split]
+    if cand and extra_splits:
+        split.update(rng.choice(cand, size=min(extra_splits, len(cand)), replace=False).tolist())
+    starts = np.array(sorted(split), np.int64)
+    chars = bwt[starts]
+    run_of = np.searchsorted(heads, starts, side="right") - 1
+    thr = run_thr[run_of]
+    cid = rng.choice(np.array(ids, np.uint8), size=len(starts))
+    interval, offset = lf_columns(chars, starts, n)
+    return pack_col_pml(bwt_r, n, chars, starts, interval, offset, cid, thr), text
+
+
+def reads_from_text(text, n_reads, read_len, sub_rate, seed, alphabet=b"ACGT", extra=b""):
+    """Substrings of `text` with substitutions; `extra` bytes (e.g. b"Nacgt")
+    are sprinkled in to exercise absent characters / no case folding."""
+    rng = np.random.default_rng(seed)
+    body = np.frombuffer(text, np.uint8)
+    out = []
+    for _ in range(n_reads):
+        m = int(read_len if np.isscalar(read_len) else rng.integers(read_len[0], read_len[1] + 1))
+        m = min(m, len(body) - 1)
+        s = int(rng.integers(0, len(body) - m)) if len(body) - m > 0 else 0
+        rd = body[s:s + m].copy()
+        rd[rd <= 1] = ord("A")
+        mut = rng.random(m) < sub_rate
+        rd[mut] = rng.choice(np.frombuffer(alphabet, np.uint8), size=int(mut.sum()))
+        if extra:
+            ex = rng.random(m) < 0.02
+            rd[ex] = rng.choice(np.frombuffer(extra, np.uint8), size=int(ex.sum()))
+        out.append(rd)
+    return out
+
+
+def concat_reads(reads):
+    off = np.zeros(len(reads) + 1, np.uint64)
+    if reads:
+        off[1:] = np.cumsum([len(r) for r in reads])
+        bases = np.concatenate(reads).astype(np.uint8) if off[-1] else np.zeros(0, np.uint8)
+    else:
+        bases = np.zeros(0, np.uint8)
+    return bases, off
+
+
+def backward_walk_reads(image, n_reads, read_len, sub_rate, seed):
+    """SURVEY.md 8(d) read recipe on any index image, vectorised over reads:
+    read[m-1-k] = char at LF^k(p0), p0 uniform; 0x01 -> 'A'; substitutions."""
+    t = unpack_col_pml(image)
+    rng = np.random.default_rng(seed)
+    idx = t["idx"].astype(np.int64)
+    n, r = int(t["n"]), int(t["r"])
+    idx_ext = np.append(idx, n)
+    p0 = rng.integers(0, n, size=n_reads)
+    i = np.searchsorted(idx, p0, side="right") - 1
+    o = p0 - idx[i]
+    out = np.zeros((n_reads, read_len), np.uint8)
+    interval = t["interval"].astype(np.int64)
+    offset = t["offset"].astype(np.int64)
+    for k in range(read_len):
+        ch = t["char"][i].copy()
+        ch[ch <= 1] = ord("A")
+        out[:, read_len - 1 - k] = ch
+        j = interval[i]
+        tt = offset[i] + o
+        while True:
+            ln = idx_ext[j + 1] - idx_ext[j]
+            ff = (tt >= ln) & (j < r - 1)
+            if not ff.any():
+                break
+            tt = np.where(ff, tt - ln, tt)
+            j = np.where(ff, j + 1, j)
+        i, o = j, tt
+    mut = rng.random(out.shape) < sub_rate
+    out[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(mut.sum()))
+    return [row for row in out]
+
+
+def write_fasta(path, reads, names=None, width=60):
+    with open(path, "wb") as f:
+        for k, rd in enumerate(reads):
+            nm = names[k] if names else f"r{k}"
+            f.write(b">" + nm.encode() + b"\n")
+            b = bytes(rd)
+            for s in range(0, len(b), width):
+                f.write(b[s:s + width] + b"\n")
+            if not b:
+                f.write(b"\n")

@@ -1,0 +1,247 @@
+"""GPU tier (-m gpu): the HIP path, called through the C-ABI (libcolbwt.so via
+ctypes), against the oracle and the committed golden vector -- bit-exact
+(integer / byte / index work, no tolerance).
+
+Edge cases follow what the reference's semantics make observable (the
+reference has no tests of its own): empty and ragged
+reads, bytes absent from the BWT, no case folding, the terminator, sub-run
+splits, unbounded succ/pred scans, run lengths beyond the 16-bit offset field,
+reads longer than 65535 bases (wide PML), corrupt files.
+"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_hip_lib(pkg):
+    path = pkg.LIB_PATH
+    assert path.endswith("col-bwt_amd/libcolbwt.so") and os.path.exists(path), "HIP extension missing"
+    return pkg.lib()
+
+
+def _check(pkg, oracle, image, reads, wide=False):
+    image = bytes(image)
+    bases, off = helpers.concat_reads(reads)
+    tbl = pkg.ColPml.from_bytes(image)
+    ref = oracle.OracleIndex(image)
+    pml, cid, st = tbl.query_batch(bases, off, wide=wide)
+    epml, ecid = ref.query_batch(bases, off, wide=wide, threads=8)
+    assert np.array_equal(pml, epml), f"PML differs at {np.flatnonzero(pml != epml)[:8]}"
+    assert np.array_equal(cid, ecid), f"col-id differs at {np.flatnonzero(cid != ecid)[:8]}"
+    tbl.close()
+    return st
+
+
+def _rand_reads(rng, n, lo, hi, alphabet=b"ACGT"):
+    return [rng.choice(np.frombuffer(alphabet, np.uint8), size=int(m)) for m in rng.integers(lo, hi + 1, size=n)]
+
+
+def test_golden_kat_values_and_text(pkg, oracle, golden_dir, tmp_path):
+    _loaded_hip_lib(pkg)
+    tbl = pkg.ColPml.load(os.path.join(golden_dir, "kat_d"))      # prefix form, pml_query.cpp:110-111
+    info = tbl.info()
+    assert (info.bwt_r, info.n, info.r, info.sigma) == (13, 22, 15, 5)
+    exp = {
+        b"GATTACA": ([5, 4, 3, 2, 1, 0, 1], [1, 3, 1, 3, 3, 1, 3]),
+        b"TTACCGATNACA": ([4, 3, 2, 1, 0, 3, 2, 1, 0, 1, 0, 1], [1, 0, 3, 0, 2, 1, 3, 1, 3, 3, 1, 3]),
+        b"CCCC": ([0, 0, 1, 0], [3, 3, 0, 3]),
+    }
+    for read, (pml, cid) in exp.items():
+        p, c = tbl.query_pml(read)
+        assert p.tolist() == pml and c.tolist() == cid
+    fa = tmp_path / "kat_d.fa"
+    shutil.copy(os.path.join(golden_dir, "kat_d.fa"), fa)
+    tbl.query_file(str(fa))
+    for ext in (".pml", ".cid"):
+        assert open(str(fa) + ext, "rb").read() == open(os.path.join(golden_dir, "kat_d.fa" + ext), "rb").read()
+
+
+def test_true_bwt_index_ragged_reads(pkg, oracle):
+    rng = np.random.default_rng(21)
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1500)
+    seqs = []
+    for _ in range(4):
+        s = base.copy()
+        mut = rng.random(1500) < 0.02
+        s[mut] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(mut.sum()))
+        seqs.append(bytes(s))
+    image, text = helpers.true_bwt_index(seqs, seed=22, extra_splits=120)
+    reads = helpers.reads_from_text(text, 400, (1, 300), 0.03, seed=23, extra=b"Nacgt")
+    reads += [np.zeros(0, np.uint8), np.frombuffer(b"T", np.uint8), np.zeros(0, np.uint8)]
+    reads += _rand_reads(rng, 100, 1, 64)
+    _check(pkg, oracle, image, reads)
+
+
+def test_empty_batch_and_all_empty_reads(pkg):
+    tbl = pkg.ColPml.from_bytes(pkg.synth_index(400, 5, 0, 1))
+    pml, cid, _ = tbl.query_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert pml.size == 0 and cid.size == 0
+    pml, cid, _ = tbl.query_batch(np.zeros(0, np.uint8), np.zeros(5, np.uint64))
+    assert pml.size == 0 and cid.size == 0
+
+
+@pytest.mark.parametrize("rows,split,seed", [(256, 0, 4), (257, 300, 3), (700, 0, 1), (50_000, 150, 2)])
+def test_synthetic_tables(pkg, oracle, rows, split, seed):
+    rng = np.random.default_rng(seed)
+    image = pkg.synth_index(rows, mean_len=6, split_permille=split, seed=seed)
+    reads = helpers.backward_walk_reads(image.tobytes(), 1000, 150, 0.01, seed=seed)   # match-heavy
+    reads += _rand_reads(rng, 600, 0, 200)                                            # mismatch-heavy, ragged
+    reads += _rand_reads(rng, 400, 1, 120, alphabet=b"ACGTN\x01acgt")                 # absent bytes, terminator
+    _check(pkg, oracle, image, reads)
+
+
+def test_rare_character_uses_jump_tables(pkg, oracle):
+    rng = np.random.default_rng(31)
+    r = 20_000
+    chars = np.tile(np.frombuffer(b"AC", np.uint8), r // 2)
+    chars[[3, 15_000, 19_999]] = ord("G")
+    chars[9_000] = 1
+    lens = rng.integers(1, 9, size=r)
+    idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    n = int(lens.sum())
+    interval, offset = helpers.lf_columns(chars, idx, n)
+    image = helpers.pack_col_pml(r, n, chars, idx, interval, offset, rng.integers(0, 256, size=r),
+                                 rng.integers(0, n, size=r))
+    _check(pkg, oracle, image, _rand_reads(rng, 800, 1, 100, alphabet=b"ACGGG\x01T"))
+
+
+def test_long_runs_len16_escape(pkg, oracle):
+    rng = np.random.default_rng(41)
+    r = 4000
+    chars = np.tile(np.frombuffer(b"ACGT", np.uint8), r // 4)
+    lens = rng.integers(1, 50, size=r)
+    lens[[5, 77, 300, 2222, r - 1]] = [65535, 70000, 200000, 65534, 66000]
+    idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    n = int(lens.sum())
+    interval, offset = helpers.lf_columns(chars, idx, n)
+    offset = offset & np.uint64(0xFFFF)            # the 16-bit field silently truncates (LF_table.hpp:39,376)
+    image = helpers.pack_col_pml(r, n, chars, idx, interval, offset, rng.integers(0, 256, size=r),
+                                 rng.integers(0, n, size=r))
+    _check(pkg, oracle, image, _rand_reads(rng, 1000, 1, 150))
+
+
+def test_wide_pml_for_reads_over_65535(pkg, oracle):
+    image = pkg.synth_index(3000, mean_len=4, split_permille=0, seed=9)
+    long_reads = helpers.backward_walk_reads(image.tobytes(), 2, 70_000, 0.0002, seed=10)
+    rng = np.random.default_rng(5)
+    st = _check(pkg, oracle, image, long_reads + _rand_reads(rng, 5, 1, 30), wide=True)
+    assert st.n_bases > 140_000
+    bases, off = helpers.concat_reads(long_reads)
+    with pytest.raises(pkg.ColbwtError):
+        pkg.ColPml.from_bytes(image).query_batch(bases, off, wide=False)
+
+
+def test_loader_rejects_corrupt_images(pkg):
+    good = pkg.synth_index(300, mean_len=5, seed=12).tobytes()
+    bad = [good[:-1],
+           good[:24] + (299).to_bytes(8, "little") + good[32:],
+           good[:32 + 18 * 10 + 6] + (10**6).to_bytes(4, "little") + good[32 + 18 * 10 + 10:],
+           good[:32 + 18 * 20 + 1] + (0).to_bytes(5, "little") + good[32 + 18 * 20 + 6:]]
+    for b in bad:
+        with pytest.raises(pkg.ColbwtError) as ei:
+            pkg.ColPml.from_bytes(b)
+        assert ei.value.code == -3
+    with pytest.raises(pkg.ColbwtError) as ei:
+        pkg.ColPml.load("/nonexistent/prefix")
+    assert ei.value.code == -2
+
+
+def test_fasta_fastq_gz_text_outputs_match_oracle(pkg, oracle, tmp_path):
+    """pml_query end to end (FASTA multi-line, FASTQ, gzip) vs the oracle's
+    restatement of the same program: byte-identical .pml/.cid."""
+    import gzip
+    rng = np.random.default_rng(51)
+    image = pkg.synth_index(5000, mean_len=6, split_permille=100, seed=52)
+    reads = helpers.backward_walk_reads(image.tobytes(), 200, 151, 0.02, seed=53) + _rand_reads(rng, 50, 0, 90)
+    names = [f"read{k}/1" for k in range(len(reads))]
+    fa = tmp_path / "reads.fa"
+    helpers.write_fasta(fa, reads, [nm + " extra comment" for nm in names], width=60)
+    fq = tmp_path / "reads.fq.gz"
+    with gzip.open(fq, "wb") as f:
+        for nm, rd in zip(names, reads):
+            f.write(b"@" + nm.encode() + b"\n" + bytes(rd) + b"\n+\n" + b"I" * len(rd) + b"\n")
+    tbl = pkg.ColPml.from_bytes(image)
+    ref = oracle.OracleIndex(image.tobytes())
+    for path in (fa, fq):
+        tbl.query_file(str(path), batch_bases=7000)            # several GPU batches
+        ref.pml_query_files(str(path), str(path) + ".opml", str(path) + ".ocid")
+        assert open(str(path) + ".pml", "rb").read() == open(str(path) + ".opml", "rb").read()
+        assert open(str(path) + ".cid", "rb").read() == open(str(path) + ".ocid", "rb").read()
+
+
+def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
+    """colbwt_query_device on torch-owned HBM buffers (the bench / multi-GPU
+    path) incl. chunked launches with absolute offsets; the device read sampler
+    feeds it."""
+    import torch
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(2_000_000, mean_len=8, split_permille=0, seed=42)
+    tbl = pkg.ColPml.from_bytes(image)
+    n_reads, m = 60_000, 150
+    d_bases = torch.zeros(n_reads * m + 32, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    tbl.synth_reads_device(n_reads, m, 10, 43, d_bases.data_ptr(), d_off.data_ptr(), s)
+    d_pml = torch.zeros(n_reads * m + 8, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(n_reads * m + 8, dtype=torch.uint8, device=dev)
+    for lo, hi in ((0, 25_000), (25_000, 60_000)):
+        st = tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
+                              d_pml.data_ptr(), d_cid.data_ptr(), 2, s, timed=True)
+        assert st.kernel_ms > 0
+    torch.cuda.synchronize()
+    off = d_off.cpu().numpy().astype(np.uint64)
+    assert off[-1] == n_reads * m and np.all(np.diff(off) == m)
+    bases = d_bases[:n_reads * m].cpu().numpy()
+    assert set(np.unique(bases).tolist()) <= set(b"ACGT")
+    ref = oracle.OracleIndex(image.tobytes())
+    epml, ecid = ref.query_batch(bases, off, threads=16)
+    assert np.array_equal(d_pml[:n_reads * m].cpu().numpy().view(np.uint16), epml)
+    assert np.array_equal(d_cid[:n_reads * m].cpu().numpy(), ecid)
+    resets = float((epml == 0).mean())
+    assert 0.02 < resets < 0.6          # the recipe's mix of extends and resets
+
+
+def test_full_scale_properties(pkg, oracle):
+    """BASELINE config C2 scale (2e8 rows): size-independent properties --
+    idempotence (two runs, identical bytes), batch-position independence (a
+    permuted sub-batch gives the same per-read values) and oracle agreement on
+    a sample.  Rows can be lowered with COLBWT_TEST_ROWS for rehearsals."""
+    import torch
+    rows = int(os.environ.get("COLBWT_TEST_ROWS", "200000000"))
+    n_reads, m = int(os.environ.get("COLBWT_TEST_READS", "2000000")), 150
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(rows, mean_len=8, split_permille=0, seed=42)
+    tbl = pkg.ColPml.from_bytes(image)
+    d_bases = torch.zeros(n_reads * m + 32, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    tbl.synth_reads_device(n_reads, m, 10, 43, d_bases.data_ptr(), d_off.data_ptr(), s)
+
+    def run():
+        p = torch.zeros(n_reads * m + 8, dtype=torch.int16, device=dev)
+        c = torch.zeros(n_reads * m + 8, dtype=torch.uint8, device=dev)
+        tbl.query_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_reads * m, p.data_ptr(), c.data_ptr(), 2, s)
+        torch.cuda.synchronize()
+        return p, c
+    p1, c1 = run()
+    p2, c2 = run()
+    assert torch.equal(p1, p2) and torch.equal(c1, c2)                       # idempotent / deterministic
+    # permuted sub-batch through the host entry point
+    rng = np.random.default_rng(1)
+    pick = rng.choice(n_reads, size=3000, replace=False)
+    hb = d_bases[:n_reads * m].view(n_reads, m)[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    off = (np.arange(3001, dtype=np.uint64) * np.uint64(m))
+    sp, sc, _ = tbl.query_batch(hb.reshape(-1), off)
+    full_p = p1[:n_reads * m].view(n_reads, m)[torch.from_numpy(pick).to(dev)].cpu().numpy().view(np.uint16)
+    full_c = c1[:n_reads * m].view(n_reads, m)[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    assert np.array_equal(sp.reshape(3000, m), full_p) and np.array_equal(sc.reshape(3000, m), full_c)
+    # oracle on the same sample
+    ref = oracle.OracleIndex(image)
+    ep, ec = ref.query_batch(hb.reshape(-1), off, threads=16)
+    assert np.array_equal(sp, ep) and np.array_equal(sc, ec)
