@@ -57,6 +57,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ColbwtError(-100, f"{LIB_PATH} not built: run __graft_entry__.build() "
                                 "(the query path has no CPU fallback)")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same
+    # soname as /opt/rocm's).  Importing torch first makes libcolbwt.so bind to
+    # that copy; loading ours first would leave torch with a second runtime
+    # that sees no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.colbwt_version.restype = C.c_char_p
