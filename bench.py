@@ -81,13 +81,13 @@ def main():
     info = tbl.info()
 
     # ---- this rank's reads, sampled on the device by backward walk (seed differs per rank)
-    d_bases = torch.zeros(n_bases + 32, dtype=torch.uint8, device=dev)
+    d_bases = torch.zeros(n_bases + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
     tbl.synth_reads_device(n_reads, m, args.sub_permille, 43 + rank, d_bases.data_ptr(), d_off.data_ptr(),
                            stream.cuda_stream)
-    d_pml = torch.zeros(n_bases + 8, dtype=torch.int16, device=dev)
-    d_cid = torch.zeros(n_bases + 8, dtype=torch.uint8, device=dev)
+    d_pml = torch.zeros(n_bases + 16, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(n_bases + 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     # ---- gather destination on rank 0 (byte views; u16 PML travels as 2 bytes)

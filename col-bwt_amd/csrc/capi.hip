@@ -101,18 +101,18 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     uint8_t *d_bases = nullptr, *d_cid = nullptr;
     uint64_t *d_off = nullptr;
     PmlT *d_pml = nullptr;
-    const uint64_t bases_alloc = (n_bases + 16 + 15) & ~15ull;
+    const uint64_t bases_alloc = (n_bases + 64 + 63) & ~63ull;  // the kernel reads whole 64-byte blocks
     float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
 
     API_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto &e : ev) API_HIP(hipEventCreate(&e));
     API_HIP(hipMalloc((void **)&d_bases, bases_alloc));
     API_HIP(hipMalloc((void **)&d_off, (n_reads + 1) * sizeof(uint64_t)));
-    API_HIP(hipMalloc((void **)&d_pml, ((n_bases + 7) & ~7ull) * sizeof(PmlT)));
-    API_HIP(hipMalloc((void **)&d_cid, (n_bases + 7) & ~7ull));
+    API_HIP(hipMalloc((void **)&d_pml, ((n_bases + 15) & ~15ull) * sizeof(PmlT)));
+    API_HIP(hipMalloc((void **)&d_cid, (n_bases + 15) & ~15ull));
 
     API_HIP(hipEventRecord(ev[0], stream));
-    API_HIP(hipMemsetAsync(d_bases + (bases_alloc - 32), 0, 32, stream));
+    API_HIP(hipMemsetAsync(d_bases + (bases_alloc - 128), 0, 128, stream));
     API_HIP(hipMemcpyAsync(d_bases, bases, n_bases, hipMemcpyHostToDevice, stream));
     API_HIP(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     API_HIP(hipEventRecord(ev[1], stream));
@@ -219,8 +219,8 @@ int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_
     if (pml_bytes != 2 && pml_bytes != 4) return fail(COLBWT_ERR_ARG, "pml_bytes must be 2 or 4");
     if (n_reads == 0) return COLBWT_OK;
     if (!d_bases || !d_read_off || !d_pml || !d_cid) return fail(COLBWT_ERR_ARG, "null device pointer");
-    if (((uintptr_t)d_bases & 15) || ((uintptr_t)d_pml & 15) || ((uintptr_t)d_cid & 7))
-        return fail(COLBWT_ERR_ARG, "d_bases/d_pml must be 16-byte aligned and d_cid 8-byte aligned");
+    if (((uintptr_t)d_bases & 15) || ((uintptr_t)d_pml & 31) || ((uintptr_t)d_cid & 15))
+        return fail(COLBWT_ERR_ARG, "d_bases/d_cid must be 16-byte aligned and d_pml 32-byte aligned");
     int rc = select_device(idx->ix.device(), g_err);
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -325,7 +325,7 @@ int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read
     int rc = select_device(idx->ix.device(), g_err);
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 16, stream));
+    API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 64, stream));
     launch_synth_reads(idx->ix.table(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
     API_HIP(hipGetLastError());
     rc = COLBWT_OK;

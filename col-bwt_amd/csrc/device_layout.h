@@ -11,7 +11,13 @@
 //       .y  offset | len16 << 16          (16+16) LF_row::offset ; run length,
 //                                          0xFFFF = "long": idx[j+1]-idx[j]
 //       .z  idx low 32 bits                      LF_row::idx
-//       .w  idx high 8 | char << 8 | col_id << 16
+//       .w  idx high 8 | char << 8 | col_id << 16 | hints << 24
+//     hints (when sigma <= 5): 2 bits per other character c, precomputed at
+//     load: how `pos < threshold(succ_c(row))` (col_bwt.hpp:560) comes out for
+//     EVERY offset inside the row -- kHintPred (always true, or no successor),
+//     kHintSucc (always false) or kHintCompare (the threshold falls inside the
+//     row: compare at query time).  Saves the threshold load and one of the two
+//     scans on almost every mismatch.
 //     row r is a sentinel with idx = n, so len(j) = idx[j+1]-idx[j] holds for
 //     the last row too (LF_table.hpp:206 special-cases it).
 //   thr[r]     u64 thresholds (col_thr::threshold), touched only on a mismatch.
@@ -32,6 +38,9 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;     // "no such run" in jump tables
 constexpr uint32_t kBlockShift = 8;         // B = 256 rows per jump block
 constexpr uint32_t kAbsent = 0xFFu;         // cmap: byte not in the BWT
 constexpr uint32_t kAlgBytesPerBase = 27;
+constexpr uint32_t kHintPred = 0, kHintSucc = 1, kHintCompare = 2;
+constexpr uint32_t kHintAllCompare = 0xAAu; // every slot = kHintCompare
+constexpr uint32_t kHintMaxSigma = 5;
 
 struct DevTable {
     const uint4 *rows;        // r + 1
@@ -43,7 +52,7 @@ struct DevTable {
     uint32_t r;
     uint32_t sigma;
     uint32_t nblk;
-    uint32_t pad_;
+    uint32_t use_hints;       // 1 when the per-row threshold hints are valid
 };
 
 }  // namespace colbwt

@@ -191,6 +191,18 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err
     tbl_.r = (uint32_t)r;
     tbl_.sigma = sigma;
     tbl_.nblk = nblk;
+    tbl_.use_hints = 0;
+
+    // ---- per-row threshold hints (only representable for sigma <= 5)
+    if (sigma <= kHintMaxSigma) {
+        HintChars hc{};
+        for (uint32_t c = 0; c < 256; ++c)
+            if (cmap[c] != kAbsent) hc.c[cmap[c]] = (uint8_t)c;
+        launch_hints(tbl_, (uint4 *)d_rows_, hc, 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(0));
+        tbl_.use_hints = 1;
+    }
     return COLBWT_OK;
 }
 

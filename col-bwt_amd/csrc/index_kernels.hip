@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "device_layout.h"
+#include "lf_device.h"
 #include "query_kernels.h"
 
 namespace colbwt {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         const uint64_t len = next_idx - idx;
         const uint32_t len16 = len < kLenLong ? (uint32_t)len : kLenLong;
         rows[i] = make_uint4(interval, offset | (len16 << 16), (uint32_t)idx,
-                             (uint32_t)(idx >> 32) | (ch << 8) | (cid << 16));
+                             (uint32_t)(idx >> 32) | (ch << 8) | (cid << 16) | (kHintAllCompare << 24));
         thr[i] = threshold;
         if (i + 1 == r) rows[r] = make_uint4(0, 0, (uint32_t)n, (uint32_t)(n >> 32));  // sentinel: idx = n
         atomicOr(&s_present[ch >> 5], 1u << (ch & 31));
@@ -116,6 +117,29 @@ __global__ __launch_bounds__(256) void block_first_last_kernel(const uint4 *__re
     }
 }
 
+// Threshold hints (device_layout.h): for row i and every other present
+// character c, how `pos < threshold(succ_c(i))` (col_bwt.hpp:552-560) comes out
+// over the row's whole position range [idx, idx+len-1].
+__global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, HintChars chars) {
+    const uint64_t i64 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i64 >= T.r) return;
+    const uint32_t i = (uint32_t)i64;
+    const uint4 w = T.rows[i];
+    const uint32_t aidx = T.cmap[row_char(w)];
+    const uint64_t lo = row_idx(w);
+    const uint64_t hi = lo + row_len(T, i, w) - 1;
+    uint32_t hints = 0;
+    for (uint32_t cidx = 0; cidx < T.sigma; ++cidx) {
+        if (cidx == aidx) continue;
+        uint4 t;
+        const uint32_t s = succ_char(T, i, chars.c[cidx], cidx, t);
+        const uint64_t thr = (s != kNone) ? T.thr[s] : T.n;   // :535 thr = n when there is no successor
+        const uint32_t code = hi < thr ? kHintPred : (lo >= thr ? kHintSucc : kHintCompare);
+        hints |= code << (2 * hint_slot(cidx, aidx));
+    }
+    rows_rw[i].w = (w.w & 0x00FFFFFFu) | (hints << 24);
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -123,9 +147,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ uint64_t d_row_idx(const uint4 &w) {
-    return (uint64_t)w.z | ((uint64_t)(w.w & 0xFFu) << 32);
-}
+__device__ __forceinline__ uint64_t d_row_idx(const uint4 &w) { return row_idx(w); }
 
 // Synthetic reads by backward walk: read[m-1-k] = char at
 // LF^k(p0).  Generator only -- results are inputs, never checked outputs.
@@ -191,6 +213,11 @@ void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uin
     if (nblk == 0) return;
     hipLaunchKernelGGL(block_first_last_kernel, dim3((nblk + 3) / 4), dim3(256), 0, stream, d_rows, r, nblk, sigma,
                        d_cmap, d_first, d_last);
+}
+
+void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream) {
+    const uint32_t blocks = (uint32_t)(((uint64_t)T.r + 255) / 256);
+    hipLaunchKernelGGL(hint_kernel, dim3(blocks), dim3(256), 0, stream, T, d_rows_rw, chars);
 }
 
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille, uint64_t seed,

@@ -1,0 +1,74 @@
+// lf_device.h -- device-side accessors of the HBM row layout (device_layout.h)
+// and the two bounded scans of the reference's move structure:
+//   LF_table::get_length  LF_table.hpp:204-207
+//   LF_table::succ_char   LF_table.hpp:286-298
+//   LF_table::pred_char   LF_table.hpp:271-283
+// Shared by the query kernel and the load-time hint kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+namespace colbwt {
+
+__device__ __forceinline__ uint32_t row_interval(const uint4 &w) { return w.x; }
+__device__ __forceinline__ uint32_t row_offset(const uint4 &w) { return w.y & 0xFFFFu; }
+__device__ __forceinline__ uint32_t row_len16(const uint4 &w) { return w.y >> 16; }
+__device__ __forceinline__ uint64_t row_idx(const uint4 &w) {
+    return (uint64_t)w.z | ((uint64_t)(w.w & 0xFFu) << 32);
+}
+__device__ __forceinline__ uint32_t row_char(const uint4 &w) { return (w.w >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t row_cid(const uint4 &w) { return (w.w >> 16) & 0xFFu; }
+__device__ __forceinline__ uint32_t row_hints(const uint4 &w) { return w.w >> 24; }
+
+// LF_table::get_length; the sentinel row r (idx = n) removes the last-row special case.
+__device__ __forceinline__ uint64_t row_len(const DevTable &T, uint32_t j, const uint4 &w) {
+    const uint32_t l16 = row_len16(w);
+    if (__builtin_expect(l16 != kLenLong, 1)) return l16;
+    const uint4 nx = T.rows[(uint64_t)j + 1];
+    return row_idx(nx) - row_idx(w);
+}
+
+// succ_char from run i whose char != c: smallest run > i holding c.  Linear
+// scan inside the 256-row jump block, then one jump-table lookup.  kNone when
+// the reference's scan would pass run r-1.
+__device__ __forceinline__ uint32_t succ_char(const DevTable &T, uint32_t i, uint32_t c, uint32_t cidx, uint4 &ws) {
+    const uint32_t blk = i >> kBlockShift;
+    const uint64_t lim64 = (((uint64_t)blk + 1) << kBlockShift) - 1;
+    const uint32_t last = lim64 < (uint64_t)(T.r - 1) ? (uint32_t)lim64 : T.r - 1;
+    for (uint32_t s = i; s < last;) {
+        ++s;
+        ws = T.rows[s];
+        if (row_char(ws) == c) return s;
+    }
+    if (blk + 1 < T.nblk) {
+        const uint32_t s = T.next_tbl[(uint64_t)(blk + 1) * T.sigma + cidx];
+        if (s != kNone) ws = T.rows[s];
+        return s;
+    }
+    return kNone;
+}
+
+// pred_char: largest run < i holding c.
+__device__ __forceinline__ uint32_t pred_char(const DevTable &T, uint32_t i, uint32_t c, uint32_t cidx, uint4 &wq) {
+    const uint32_t blk = i >> kBlockShift;
+    const uint32_t first = blk << kBlockShift;
+    for (uint32_t q = i; q > first;) {
+        --q;
+        wq = T.rows[q];
+        if (row_char(wq) == c) return q;
+    }
+    if (blk > 0) {
+        const uint32_t q = T.prev_tbl[(uint64_t)blk * T.sigma + cidx];
+        if (q != kNone) wq = T.rows[q];
+        return q;
+    }
+    return kNone;
+}
+
+// Slot of character index cidx among the characters other than the row's own
+// (aidx): 2 hint bits per slot, 4 slots => usable when sigma <= 5.
+__device__ __forceinline__ uint32_t hint_slot(uint32_t cidx, uint32_t aidx) { return cidx < aidx ? cidx : cidx - 1; }
+
+}  // namespace colbwt

@@ -27,6 +27,12 @@ void launch_relayout(const uint8_t *d_raw, uint64_t row0, uint64_t count, uint64
 void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uint32_t sigma,
                              const uint8_t *d_cmap, uint32_t *d_first, uint32_t *d_last, hipStream_t stream);
 
+// Threshold hints (device_layout.h); chars.c[cidx] = the byte with dense index cidx.
+struct HintChars {
+    uint8_t c[8];
+};
+void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream);
+
 // Backward-walk read sampler (synthetic benchmark input).
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                         uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);

@@ -13,86 +13,61 @@
 //     on (device_layout.h); that one load also carries char, col id, the next
 //     interval/offset, idx (for pos) and the run length, so the following
 //     step needs no further table access unless it fast-forwards / mismatches;
-//   * read bytes are pulled 16 at a time through a 128-bit shift register;
-//   * PML (u16) and col id (u8) are collected for 8 bases in registers and
-//     leave as one 16-byte and one 8-byte aligned store.
+//   * HBM serves every random 16-byte row load as one 128-byte line fill
+//     (calibrated with tools/gather_bench: two loads in the two 64-byte halves
+//     of a line cost ONE TCC_EA0_RDREQ), so what matters is the number of
+//     distinct lines a step touches: rows are 16-byte aligned (8 per line), the
+//     threshold decision is pre-resolved into 2-bit hints inside the row, and
+//     a mismatch runs only the scan whose result it will use;
+//   * read bytes: each lane stages 64 bytes of its read in LDS per refill
+//     (4 x 16 B from one line) and shifts them out of a 128-bit register;
+//   * PML (u16) and col id (u8) are collected for 16 bases in registers and
+//     leave as 32-byte and 16-byte aligned stores (whole 32-byte sectors).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "device_layout.h"
+#include "lf_device.h"
 #include "query_kernels.h"
 
 namespace colbwt {
 
-__device__ __forceinline__ uint32_t row_interval(const uint4 &w) { return w.x; }
-__device__ __forceinline__ uint32_t row_offset(const uint4 &w) { return w.y & 0xFFFFu; }
-__device__ __forceinline__ uint32_t row_len16(const uint4 &w) { return w.y >> 16; }
-__device__ __forceinline__ uint64_t row_idx(const uint4 &w) {
-    return (uint64_t)w.z | ((uint64_t)(w.w & 0xFFu) << 32);
-}
-__device__ __forceinline__ uint32_t row_char(const uint4 &w) { return (w.w >> 8) & 0xFFu; }
-__device__ __forceinline__ uint32_t row_cid(const uint4 &w) { return (w.w >> 16) & 0xFFu; }
-
-// LF_table::get_length (LF_table.hpp:204-207); the sentinel row r (idx = n)
-// removes the last-row special case.
-__device__ __forceinline__ uint64_t row_len(const DevTable &T, uint32_t j, const uint4 &w) {
-    uint32_t l16 = row_len16(w);
-    if (__builtin_expect(l16 != kLenLong, 1)) return l16;
-    uint4 nx = T.rows[(uint64_t)j + 1];
-    return row_idx(nx) - row_idx(w);
-}
-
-// LF_table::succ_char (LF_table.hpp:286-298) from run i whose char != c:
-// smallest run > i holding c.  Linear scan inside the 256-row block, then one
-// jump-table lookup.  Returns kNone when the scan would pass run r-1.
-__device__ __forceinline__ uint32_t succ_char(const DevTable &T, uint32_t i, uint32_t c,
-                                              uint32_t cidx, uint4 &ws) {
-    const uint32_t blk = i >> kBlockShift;
-    uint64_t lim64 = (((uint64_t)blk + 1) << kBlockShift) - 1;
-    const uint32_t last = lim64 < (uint64_t)(T.r - 1) ? (uint32_t)lim64 : T.r - 1;
-    for (uint32_t s = i; s < last;) {
-        ++s;
-        ws = T.rows[s];
-        if (row_char(ws) == c) return s;
-    }
-    if (blk + 1 < T.nblk) {
-        uint32_t s = T.next_tbl[(uint64_t)(blk + 1) * T.sigma + cidx];
-        if (s != kNone) ws = T.rows[s];
-        return s;
-    }
-    return kNone;
-}
-
-// LF_table::pred_char (LF_table.hpp:271-283): largest run < i holding c.
-__device__ __forceinline__ uint32_t pred_char(const DevTable &T, uint32_t i, uint32_t c,
-                                              uint32_t cidx, uint4 &wq) {
-    const uint32_t blk = i >> kBlockShift;
-    const uint32_t first = blk << kBlockShift;
-    for (uint32_t q = i; q > first;) {
-        --q;
-        wq = T.rows[q];
-        if (row_char(wq) == c) return q;
-    }
-    if (blk > 0) {
-        uint32_t q = T.prev_tbl[(uint64_t)blk * T.sigma + cidx];
-        if (q != kNone) wq = T.rows[q];
-        return q;
-    }
-    return kNone;
-}
-
-// col_pml::threshold_step (col_bwt.hpp:531-574), the !MULTI_THREAD arm: pred
-// is only searched when pos < thr (same result as the threaded arm).
+// col_pml::threshold_step (col_bwt.hpp:531-574).  Reference order: find succ,
+// take its threshold, then pred only when pos < thr (the !MULTI_THREAD arm;
+// the threaded arm computes the same values).  The per-row hint tells in
+// advance how `pos < thr` comes out, so only the scan that decides the result
+// runs; kHintCompare falls back to the reference's exact sequence.
 __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t *s_cmap,
                                                uint32_t &i, uint64_t &o, uint4 &w, uint32_t c) {
     const uint32_t cidx = s_cmap[c];
     if (cidx == kAbsent) return;  // c occurs nowhere: (interval, offset) unchanged (:533-534)
+    uint32_t hint = kHintCompare;
+    if (T.use_hints) hint = (row_hints(w) >> (2 * hint_slot(cidx, s_cmap[row_char(w)]))) & 3u;
+    uint4 t;
+    if (hint == kHintPred) {
+        // pos < thr for every offset of this row (or no successor, thr = n :535): pred wins if it exists
+        const uint32_t q = pred_char(T, i, c, cidx, t);      // :562
+        if (q != kNone) {                                     // :565-569
+            i = q;
+            o = row_len(T, q, t) - 1;                         // LF_table.hpp:282
+            w = t;
+            return;
+        }
+        const uint32_t s = succ_char(T, i, c, cidx, t);      // :548
+        if (s != kNone) { i = s; o = 0; w = t; }              // :552-557
+        return;
+    }
+    if (hint == kHintSucc) {
+        // pos >= thr(succ) for every offset of this row: the successor exists and wins (:552-557)
+        const uint32_t s = succ_char(T, i, c, cidx, t);
+        if (s != kNone) { i = s; o = 0; w = t; }
+        return;
+    }
     const uint64_t pos = row_idx(w) + o;  // LF_table::to_idx (LF_table.hpp:214-217)
     uint64_t thr = T.n;                   // :535
     uint32_t ni = i;
     uint64_t no = o;
     uint4 nw = w;
-    uint4 t;
     const uint32_t s = succ_char(T, i, c, cidx, t);  // :548
     if (s != kNone) {                                 // :552-557
         thr = T.thr[s];
@@ -113,12 +88,18 @@ __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t 
     w = nw;
 }
 
-// 128-bit shift register holding up to 16 read bytes; the next byte to
-// consume (highest address) sits in the top byte.
+// Read bytes: 64 bytes of the lane's read live in LDS (one 64-byte-aligned
+// block of `bases`, 4 x uint4 from one HBM line); a 128-bit shift register
+// holds the 16 bytes being consumed, next byte (highest address) on top.
 struct ReadWindow {
     uint64_t lo, hi;
-    __device__ __forceinline__ void load(const uint8_t *bases, uint64_t g) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bases + (g & ~(uint64_t)15));
+    __device__ __forceinline__ void refill(uint4 (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bases + (g & ~(uint64_t)63));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_rd[q][threadIdx.x] = src[q];
+    }
+    __device__ __forceinline__ void load(uint4 (*s_rd)[kQueryBlock], uint64_t g) {
+        const uint4 v = s_rd[(g >> 4) & 3][threadIdx.x];
         lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
         hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
     }
@@ -128,40 +109,52 @@ struct ReadWindow {
         if (sh) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; }
     }
     __device__ __forceinline__ uint32_t pop() {
-        uint32_t c = (uint32_t)(hi >> 56);
+        const uint32_t c = (uint32_t)(hi >> 56);
         hi = (hi << 8) | (lo >> 56);
         lo <<= 8;
         return c;
     }
 };
 
-// Output collector: 8 bases per flush, flush boundaries at global element
-// indices that are multiples of 8 so full flushes are aligned vector stores.
+// Output collector: kFlush = 16 bases per flush, flush boundaries at global
+// element indices that are multiples of 16, so a full flush is aligned vector
+// stores covering whole 32-byte sectors; partial groups (read ends) go out
+// element by element.
+constexpr uint32_t kFlush = 16;
+
 template <typename PmlT>
 struct OutAcc;
 
 template <>
 struct OutAcc<uint16_t> {
-    uint64_t plo = 0, phi = 0, c8 = 0;
+    uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, c0 = 0, c1 = 0;
     uint32_t cnt = 0;
     __device__ __forceinline__ void push(uint32_t L, uint32_t cid) {
-        phi = (phi << 16) | (plo >> 48);
-        plo = (plo << 16) | (uint64_t)(L & 0xFFFFu);
-        c8 = (c8 << 8) | (uint64_t)cid;
+        p3 = (p3 << 16) | (p2 >> 48);
+        p2 = (p2 << 16) | (p1 >> 48);
+        p1 = (p1 << 16) | (p0 >> 48);
+        p0 = (p0 << 16) | (uint64_t)(L & 0xFFFFu);
+        c1 = (c1 << 8) | (c0 >> 56);
+        c0 = (c0 << 8) | (uint64_t)cid;
         ++cnt;
     }
     __device__ __forceinline__ void flush(uint16_t *pml, uint8_t *cid, uint64_t g) {
-        if (cnt == 8) {
-            uint4 v = make_uint4((uint32_t)plo, (uint32_t)(plo >> 32), (uint32_t)phi, (uint32_t)(phi >> 32));
-            *reinterpret_cast<uint4 *>(pml + g) = v;
-            *reinterpret_cast<uint2 *>(cid + g) = make_uint2((uint32_t)c8, (uint32_t)(c8 >> 32));
+        if (cnt == kFlush) {
+            uint4 *dst = reinterpret_cast<uint4 *>(pml + g);
+            dst[0] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
+            dst[1] = make_uint4((uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32));
+            *reinterpret_cast<uint4 *>(cid + g) =
+                make_uint4((uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32));
         } else {
             for (uint32_t e = 0; e < cnt; ++e) {
-                pml[g + e] = (uint16_t)plo;
-                cid[g + e] = (uint8_t)c8;
-                plo = (plo >> 16) | (phi << 48);
-                phi >>= 16;
-                c8 >>= 8;
+                pml[g + e] = (uint16_t)p0;
+                cid[g + e] = (uint8_t)c0;
+                p0 = (p0 >> 16) | (p1 << 48);
+                p1 = (p1 >> 16) | (p2 << 48);
+                p2 = (p2 >> 16) | (p3 << 48);
+                p3 >>= 16;
+                c0 = (c0 >> 8) | (c1 << 56);
+                c1 >>= 8;
             }
         }
         cnt = 0;
@@ -169,36 +162,9 @@ struct OutAcc<uint16_t> {
 };
 
 template <>
-struct OutAcc<uint32_t> {  // reads longer than 65535 bases: wide PML, same cadence
-    uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, c8 = 0;
-    uint32_t cnt = 0;
-    __device__ __forceinline__ void push(uint32_t L, uint32_t cid) {
-        p3 = (p3 << 32) | (p2 >> 32);
-        p2 = (p2 << 32) | (p1 >> 32);
-        p1 = (p1 << 32) | (p0 >> 32);
-        p0 = (p0 << 32) | (uint64_t)L;
-        c8 = (c8 << 8) | (uint64_t)cid;
-        ++cnt;
-    }
-    __device__ __forceinline__ void flush(uint32_t *pml, uint8_t *cid, uint64_t g) {
-        if (cnt == 8) {
-            uint4 *dst = reinterpret_cast<uint4 *>(pml + g);
-            dst[0] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
-            dst[1] = make_uint4((uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32));
-            *reinterpret_cast<uint2 *>(cid + g) = make_uint2((uint32_t)c8, (uint32_t)(c8 >> 32));
-        } else {
-            for (uint32_t e = 0; e < cnt; ++e) {
-                pml[g + e] = (uint32_t)p0;
-                cid[g + e] = (uint8_t)c8;
-                p0 = (p0 >> 32) | (p1 << 32);
-                p1 = (p1 >> 32) | (p2 << 32);
-                p2 = (p2 >> 32) | (p3 << 32);
-                p3 >>= 32;
-                c8 >>= 8;
-            }
-        }
-        cnt = 0;
-    }
+struct OutAcc<uint32_t> {  // reads longer than 65535 bases: wide PML, stored per base
+    __device__ __forceinline__ void push(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void flush(uint32_t *, uint8_t *, uint64_t) {}
 };
 
 template <typename PmlT>
@@ -206,6 +172,8 @@ __global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, cons
                                                                 const uint64_t *__restrict__ read_off,
                                                                 uint64_t n_reads, PmlT *__restrict__ pml,
                                                                 uint8_t *__restrict__ cid) {
+    constexpr bool kWide = sizeof(PmlT) == 4;
+    __shared__ uint4 s_rd[4][kQueryBlock];
     __shared__ uint8_t s_cmap[256];
     for (uint32_t t = threadIdx.x; t < 256; t += kQueryBlock) s_cmap[t] = T.cmap[t];
     __syncthreads();
@@ -226,7 +194,8 @@ __global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, cons
     OutAcc<PmlT> acc;
     {
         const uint64_t g = off + m - 1;
-        win.load(bases, g);
+        win.refill(s_rd, bases, g);
+        win.load(s_rd, g);
         win.drop_top(15u - (uint32_t)(g & 15));
     }
 
@@ -240,10 +209,18 @@ __global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, cons
             L = 0;                                   // :521
             threshold_step(T, s_cmap, i, o, w, c);   // :522
         }
-        acc.push(L, col_id);                         // :525
-        if ((g & 7) == 0 || k == 0) acc.flush(pml, cid, g);
+        if (kWide) {                                 // :525
+            pml[g] = (PmlT)L;
+            cid[g] = (uint8_t)col_id;
+        } else {
+            acc.push(L, col_id);
+            if ((g & (kFlush - 1)) == 0 || k == 0) acc.flush(pml, cid, g);
+        }
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
-        if ((g & 15) == 0) win.load(bases, g - 1);
+        if ((g & 15) == 0) {
+            if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
+            win.load(s_rd, g - 1);
+        }
 
         // LF_table::LF (LF_table.hpp:251-262)
         uint32_t j = row_interval(w);                // :253

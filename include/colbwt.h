@@ -100,8 +100,9 @@ int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64
 
 /* Same computation with every buffer already resident in HBM on the index's
  * device (the benchmark / multi-GPU path).  Requirements: d_bases has at least
- * 16 readable bytes past read_off[n_reads]; d_bases and d_pml are 16-byte
- * aligned, d_cid 8-byte aligned; pml_bytes is 2 or 4.  `hip_stream` is a
+ * 64 readable bytes past read_off[n_reads] (the kernel reads whole 64-byte
+ * blocks); d_bases and d_cid are 16-byte aligned, d_pml 32-byte aligned;
+ * pml_bytes is 2 or 4 (2 needs every read <= 65535 bases).  `hip_stream` is a
  * hipStream_t (NULL = default stream); the call is asynchronous unless
  * `stats` is non-NULL, in which case it records HIP events on the stream,
  * synchronises it and fills kernel_ms. */
@@ -131,7 +132,7 @@ int colbwt_synth_index(uint64_t rows, uint32_t mean_len, uint32_t split_permille
                        void *out, uint64_t out_len);
 /* Backward-walk reads sampled ON THE DEVICE from the loaded index:
  * read[m-1-k] = char at LF^k(p0), p0 uniform; 0x01 -> 'A'; substitutions at
- * `sub_permille`/1000.  Writes n_reads*read_len bytes (+16 pad bytes zeroed)
+ * `sub_permille`/1000.  Writes n_reads*read_len bytes (+64 pad bytes zeroed)
  * to d_bases and n_reads+1 offsets to d_read_off (both device pointers). */
 int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len,
                               uint32_t sub_permille, uint64_t seed, uint8_t *d_bases,

@@ -102,6 +102,11 @@ def main():
     reads = rand_reads(rng, 60, 1, 60, alphabet=b"ACGGG\x01T")
     check(img, reads, "rare_char")
 
+    # 4b. threshold hints: thresholds inside rows (sigma <= 5, hints on) and sigma = 7 (hints off)
+    for label, alpha in (("hints_sigma4", b"ACGT"), ("hints_sigma5", b"\x01ACGT"), ("nohints_sigma7", b"\x01ACGNTac")):
+        img = helpers.random_table(rng, 1500, alphabet=alpha)
+        check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label)
+
     # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
     r = 600
     chars = np.tile(np.frombuffer(b"ACGT", np.uint8), r // 4)

@@ -105,6 +105,34 @@ def true_bwt_index(seqs, seed=0, extra_splits=20, ids=(0, 0, 0, 1, 2, 3, 17, 200
     return pack_col_pml(bwt_r, n, chars, starts, interval, offset, cid, thr), text
 
 
+def random_table(rng, r, alphabet=b"ACGT", max_len=9, split_prob=0.1, thr_inside=True):
+    """A random but self-consistent move table over `alphabet` (any sigma):
+    random run characters (repeats allowed = sub-run splits), lengths, ids;
+    thresholds shared by the sub-runs of a BWT run, some placed inside nearby
+    rows so the `pos < thr` comparison depends on the offset."""
+    alpha = np.frombuffer(alphabet, np.uint8)
+    chars = rng.choice(alpha, size=r)
+    rep = rng.random(r) < split_prob
+    for k in range(1, r):
+        if rep[k]:
+            chars[k] = chars[k - 1]
+    lens = rng.integers(1, max_len + 1, size=r)
+    idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    n = int(lens.sum())
+    interval, offset = lf_columns(chars, idx, n)
+    thr = rng.integers(0, n, size=r)
+    if thr_inside:
+        near = rng.random(r) < 0.5
+        back = rng.integers(0, 6, size=r)
+        j = np.maximum(np.arange(r) - back, 0)
+        thr = np.where(near, idx[j] + rng.integers(0, max_len, size=r) % lens[j], thr)
+    heads = np.concatenate(([True], chars[1:] != chars[:-1]))
+    run_of = np.cumsum(heads) - 1
+    thr = thr[np.flatnonzero(heads)][run_of]
+    cid = rng.integers(0, 256, size=r)
+    return pack_col_pml(int(heads.sum()), n, chars, idx, interval, offset, cid, thr)
+
+
 def reads_from_text(text, n_reads, read_len, sub_rate, seed, alphabet=b"ACGT", extra=b""):
     """Substrings of `text` with substitutions; `extra` bytes (e.g. b"Nacgt")
     are sprinkled in to exercise absent characters / no case folding."""

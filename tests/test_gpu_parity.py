@@ -111,6 +111,15 @@ def test_rare_character_uses_jump_tables(pkg, oracle):
     _check(pkg, oracle, image, _rand_reads(rng, 800, 1, 100, alphabet=b"ACGGG\x01T"))
 
 
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"\x01ACGT", b"\x01ACGNTac"])
+def test_threshold_hints_on_and_off(pkg, oracle, alphabet):
+    """Thresholds that fall inside rows (offset-dependent `pos < thr`,
+    col_bwt.hpp:560) with the 2-bit hints active (sigma <= 5) and inactive."""
+    rng = np.random.default_rng(len(alphabet))
+    image = helpers.random_table(rng, 30_000, alphabet=alphabet)
+    _check(pkg, oracle, image, _rand_reads(rng, 1500, 1, 120, alphabet=alphabet + b"N"))
+
+
 def test_long_runs_len16_escape(pkg, oracle):
     rng = np.random.default_rng(41)
     r = 4000
@@ -184,12 +193,12 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
     image = pkg.synth_index(2_000_000, mean_len=8, split_permille=0, seed=42)
     tbl = pkg.ColPml.from_bytes(image)
     n_reads, m = 60_000, 150
-    d_bases = torch.zeros(n_reads * m + 32, dtype=torch.uint8, device=dev)
+    d_bases = torch.zeros(n_reads * m + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     tbl.synth_reads_device(n_reads, m, 10, 43, d_bases.data_ptr(), d_off.data_ptr(), s)
-    d_pml = torch.zeros(n_reads * m + 8, dtype=torch.int16, device=dev)
-    d_cid = torch.zeros(n_reads * m + 8, dtype=torch.uint8, device=dev)
+    d_pml = torch.zeros(n_reads * m + 16, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(n_reads * m + 16, dtype=torch.uint8, device=dev)
     for lo, hi in ((0, 25_000), (25_000, 60_000)):
         st = tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
                               d_pml.data_ptr(), d_cid.data_ptr(), 2, s, timed=True)
@@ -218,14 +227,14 @@ def test_full_scale_properties(pkg, oracle):
     dev = torch.device("cuda", 0)
     image = pkg.synth_index(rows, mean_len=8, split_permille=0, seed=42)
     tbl = pkg.ColPml.from_bytes(image)
-    d_bases = torch.zeros(n_reads * m + 32, dtype=torch.uint8, device=dev)
+    d_bases = torch.zeros(n_reads * m + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream().cuda_stream
     tbl.synth_reads_device(n_reads, m, 10, 43, d_bases.data_ptr(), d_off.data_ptr(), s)
 
     def run():
-        p = torch.zeros(n_reads * m + 8, dtype=torch.int16, device=dev)
-        c = torch.zeros(n_reads * m + 8, dtype=torch.uint8, device=dev)
+        p = torch.zeros(n_reads * m + 16, dtype=torch.int16, device=dev)
+        c = torch.zeros(n_reads * m + 16, dtype=torch.uint8, device=dev)
         tbl.query_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_reads * m, p.data_ptr(), c.data_ptr(), 2, s)
         torch.cuda.synchronize()
         return p, c

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condenses a gpurun_out/prof_<tag>/ directory (tools/profile_round.sh) into
+profiles/<tag>_kernel_stats.csv + profiles/<tag>_summary.json.
+
+HBM traffic per launch follows MI355X_MICROARCH.md (HBM / rocprofv3 PMC):
+FETCH_SIZE and WRITE_SIZE are collected in separate passes, are in KiB, and
+FETCH_SIZE = TCC_EA0_RDREQ x 64 B.  For THIS kernel's access pattern (random
+16-byte row loads: one 64-byte request each, cross-checked against
+TCC_EA0_RDREQ and against the known load count of tools/gather_bench) the
+reading is taken as exact, not doubled -- the x2 correction in the guide is
+for wide coalesced streams whose 128-byte requests are tallied at 64 bytes.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def main():
+    tag = sys.argv[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(root, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    summary = {"tag": tag, "kernels": {}}
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            if "colbwt" in r["Name"]:
+                summary["kernels"].setdefault(r["Name"][:80], {}).update(
+                    calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), total_ns=float(r["TotalDurationNs"]))
+    for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*counter_collection.csv"))):
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(f)):
+            if "colbwt" not in r["Kernel_Name"]:
+                continue
+            a = agg[(r["Kernel_Name"][:80], r["Counter_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+        for (k, c), (v, n) in agg.items():
+            summary["kernels"].setdefault(k, {}).setdefault("pmc_per_launch", {})[c] = v / n
+    for k, d in summary["kernels"].items():
+        p = d.get("pmc_per_launch", {})
+        if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+            d["hbm_read_bytes_per_launch"] = p["FETCH_SIZE"] * 1024
+            d["hbm_write_bytes_per_launch"] = p["WRITE_SIZE"] * 1024
+            d["hbm_bytes_per_launch"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+    bt = os.path.join(src, "bench_trace.json")
+    if os.path.exists(bt):
+        try:
+            summary["bench_line_under_trace"] = json.loads(open(bt).read().strip().splitlines()[-1])
+        except Exception:
+            pass
+    json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+    q = [d for k, d in summary["kernels"].items() if "pml_query_kernel" in k]
+    if q and "hbm_bytes_per_launch" in q[0] and len(sys.argv) > 2 and sys.argv[2] == "--set-traffic":
+        json.dump({"tag": tag, "hbm_bytes_per_launch": q[0]["hbm_bytes_per_launch"],
+                   "hbm_read_bytes_per_launch": q[0]["hbm_read_bytes_per_launch"],
+                   "hbm_write_bytes_per_launch": q[0]["hbm_write_bytes_per_launch"]},
+                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print(json.dumps(summary["kernels"], indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
