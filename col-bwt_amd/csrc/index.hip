@@ -93,10 +93,13 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err
     const uint8_t *rows_disk = bytes + kHeaderBytes;
     const uint32_t nblk = (uint32_t)((r + (1u << kBlockShift) - 1) >> kBlockShift);
 
-    HIP_TRY(hipMalloc(&d_rows_, (r + 1) * sizeof(uint4)));
+    // r rows + the sentinel, padded to whole 128-byte lines (8 rows) so line-wide loads stay in bounds
+    const uint64_t rows_alloc = ((r + 1 + 7) & ~7ull) * sizeof(uint4);
+    HIP_TRY(hipMalloc(&d_rows_, rows_alloc));
+    HIP_TRY(hipMemset(d_rows_, 0, rows_alloc));
     HIP_TRY(hipMalloc(&d_thr_, r * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&d_cmap_, 256));
-    device_bytes_ = (r + 1) * sizeof(uint4) + r * sizeof(uint64_t) + 256;
+    device_bytes_ = rows_alloc + r * sizeof(uint64_t) + 256;
 
     // ---- upload packed rows chunk by chunk and re-lay them out on the device
     RelayoutReport *d_report = nullptr;

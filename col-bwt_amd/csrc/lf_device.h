@@ -30,17 +30,40 @@ __device__ __forceinline__ uint64_t row_len(const DevTable &T, uint32_t j, const
     return row_idx(nx) - row_idx(w);
 }
 
-// succ_char from run i whose char != c: smallest run > i holding c.  Linear
-// scan inside the 256-row jump block, then one jump-table lookup.  kNone when
-// the reference's scan would pass run r-1.
+// Rows are 16 bytes, 8 per 128-byte HBM line.  The scans below walk line by
+// line: the characters (.w dwords) of all 8 rows of a line are fetched by 8
+// independent loads off ONE base address (immediate offsets) and compared in
+// registers, then the matching row is loaded whole.  Inside the line that
+// already holds row i these are cache hits, so a mismatch usually costs no
+// extra HBM line.  (Loads are unconditional: a predicated load is serialised
+// behind its own branch + s_waitcnt.  The rows array is padded to whole lines.)
+__device__ __forceinline__ void line_chars(const DevTable &T, uint32_t line_first_row, uint32_t (&ch)[8]) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(T.rows) + (uint64_t)line_first_row * 4 + 3;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; ++q) ch[q] = (p[q * 4] >> 8) & 0xFFu;
+}
+
+// succ_char from run i whose char != c: smallest run > i holding c.  Scan
+// inside the 256-row jump block, then one jump-table lookup.  kNone when the
+// reference's scan (LF_table.hpp:286-298) would pass run r-1.
 __device__ __forceinline__ uint32_t succ_char(const DevTable &T, uint32_t i, uint32_t c, uint32_t cidx, uint4 &ws) {
     const uint32_t blk = i >> kBlockShift;
     const uint64_t lim64 = (((uint64_t)blk + 1) << kBlockShift) - 1;
     const uint32_t last = lim64 < (uint64_t)(T.r - 1) ? (uint32_t)lim64 : T.r - 1;
-    for (uint32_t s = i; s < last;) {
-        ++s;
-        ws = T.rows[s];
-        if (row_char(ws) == c) return s;
+    for (uint64_t s0 = (uint64_t)i + 1; s0 <= last;) {
+        const uint32_t lb = (uint32_t)s0 & ~7u;
+        const uint32_t lo_q = (uint32_t)s0 & 7u;
+        const uint32_t hi_q = (lb + 7u < last ? lb + 7u : last) - lb;
+        uint32_t ch[8];
+        line_chars(T, lb, ch);
+        uint32_t hit = 8;
+#pragma unroll
+        for (uint32_t q = 8; q-- > 0;) hit = (ch[q] == c && q >= lo_q && q <= hi_q) ? q : hit;  // lowest match
+        if (hit < 8) {
+            ws = T.rows[lb + hit];
+            return lb + hit;
+        }
+        s0 = (uint64_t)lb + 8;
     }
     if (blk + 1 < T.nblk) {
         const uint32_t s = T.next_tbl[(uint64_t)(blk + 1) * T.sigma + cidx];
@@ -50,14 +73,24 @@ __device__ __forceinline__ uint32_t succ_char(const DevTable &T, uint32_t i, uin
     return kNone;
 }
 
-// pred_char: largest run < i holding c.
+// pred_char (LF_table.hpp:271-283): largest run < i holding c.
 __device__ __forceinline__ uint32_t pred_char(const DevTable &T, uint32_t i, uint32_t c, uint32_t cidx, uint4 &wq) {
     const uint32_t blk = i >> kBlockShift;
-    const uint32_t first = blk << kBlockShift;
-    for (uint32_t q = i; q > first;) {
-        --q;
-        wq = T.rows[q];
-        if (row_char(wq) == c) return q;
+    const uint32_t first = blk << kBlockShift;   // a multiple of 256, hence of 8
+    for (uint32_t q0 = i; q0 > first;) {          // candidates are rows first .. q0-1
+        const uint32_t top = q0 - 1;
+        const uint32_t lb = top & ~7u;
+        const uint32_t hi_q = top & 7u;
+        uint32_t ch[8];
+        line_chars(T, lb, ch);
+        uint32_t hit = 8;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) hit = (ch[q] == c && q <= hi_q) ? q : hit;  // highest match
+        if (hit < 8) {
+            wq = T.rows[lb + hit];
+            return lb + hit;
+        }
+        q0 = lb;
     }
     if (blk > 0) {
         const uint32_t q = T.prev_tbl[(uint64_t)blk * T.sigma + cidx];
@@ -66,6 +99,7 @@ __device__ __forceinline__ uint32_t pred_char(const DevTable &T, uint32_t i, uin
     }
     return kNone;
 }
+
 
 // Slot of character index cidx among the characters other than the row's own
 // (aidx): 2 hint bits per slot, 4 slots => usable when sigma <= 5.

@@ -20,7 +20,7 @@
 //     threshold decision is pre-resolved into 2-bit hints inside the row, and
 //     a mismatch runs only the scan whose result it will use;
 //   * read bytes: each lane stages 64 bytes of its read in LDS per refill
-//     (4 x 16 B from one line) and shifts them out of a 128-bit register;
+//     (4 x 16 B from one line) and picks one byte per step from there;
 //   * PML (u16) and col id (u8) are collected for 16 bases in registers and
 //     leave as 32-byte and 16-byte aligned stores (whole 32-byte sectors).
 #include <hip/hip_runtime.h>
@@ -88,31 +88,26 @@ __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t 
     w = nw;
 }
 
-// Read bytes: 64 bytes of the lane's read live in LDS (one 64-byte-aligned
-// block of `bases`, 4 x uint4 from one HBM line); a 128-bit shift register
-// holds the 16 bytes being consumed, next byte (highest address) on top.
+// Read bytes: 64 bytes of the lane's read (one 64-byte-aligned block of `bases`,
+// 4 x uint4 from one HBM line) are staged in LDS, dword-major ([16][block] so
+// consecutive lanes hit consecutive banks); each step reads its byte from there.
 struct ReadWindow {
-    uint64_t lo, hi;
-    __device__ __forceinline__ void refill(uint4 (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
+    __device__ __forceinline__ void refill(uint32_t (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
         const uint4 *src = reinterpret_cast<const uint4 *>(bases + (g & ~(uint64_t)63));
+        uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s_rd[q][threadIdx.x] = src[q];
+        for (int q = 0; q < 4; ++q) v[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s_rd[4 * q + 0][threadIdx.x] = v[q].x;
+            s_rd[4 * q + 1][threadIdx.x] = v[q].y;
+            s_rd[4 * q + 2][threadIdx.x] = v[q].z;
+            s_rd[4 * q + 3][threadIdx.x] = v[q].w;
+        }
     }
-    __device__ __forceinline__ void load(uint4 (*s_rd)[kQueryBlock], uint64_t g) {
-        const uint4 v = s_rd[(g >> 4) & 3][threadIdx.x];
-        lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
-        hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-    }
-    __device__ __forceinline__ void drop_top(uint32_t nbytes) {  // nbytes in [0,15]
-        uint32_t sh = nbytes * 8;
-        if (sh >= 64) { hi = lo; lo = 0; sh -= 64; }
-        if (sh) { hi = (hi << sh) | (lo >> (64 - sh)); lo <<= sh; }
-    }
-    __device__ __forceinline__ uint32_t pop() {
-        const uint32_t c = (uint32_t)(hi >> 56);
-        hi = (hi << 8) | (lo >> 56);
-        lo <<= 8;
-        return c;
+    __device__ __forceinline__ uint32_t get(uint32_t (*s_rd)[kQueryBlock], uint64_t g) {
+        const uint32_t b = (uint32_t)g & 63u;
+        return (s_rd[b >> 2][threadIdx.x] >> (8 * (b & 3u))) & 0xFFu;
     }
 };
 
@@ -167,13 +162,16 @@ struct OutAcc<uint32_t> {  // reads longer than 65535 bases: wide PML, stored pe
     __device__ __forceinline__ void flush(uint32_t *, uint8_t *, uint64_t) {}
 };
 
+// Register budget: <= 64 VGPRs and <= 80 SGPRs keep 8 waves per SIMD resident
+// (MI355X_MICROARCH.md: residency of 256-thread blocks by .sgpr_count).
 template <typename PmlT>
-__global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
+__global__ __launch_bounds__(kQueryBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
+void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
                                                                 const uint64_t *__restrict__ read_off,
                                                                 uint64_t n_reads, PmlT *__restrict__ pml,
                                                                 uint8_t *__restrict__ cid) {
     constexpr bool kWide = sizeof(PmlT) == 4;
-    __shared__ uint4 s_rd[4][kQueryBlock];
+    __shared__ uint32_t s_rd[16][kQueryBlock];
     __shared__ uint8_t s_cmap[256];
     for (uint32_t t = threadIdx.x; t < 256; t += kQueryBlock) s_cmap[t] = T.cmap[t];
     __syncthreads();
@@ -192,16 +190,11 @@ __global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, cons
 
     ReadWindow win;
     OutAcc<PmlT> acc;
-    {
-        const uint64_t g = off + m - 1;
-        win.refill(s_rd, bases, g);
-        win.load(s_rd, g);
-        win.drop_top(15u - (uint32_t)(g & 15));
-    }
+    win.refill(s_rd, bases, off + m - 1);
 
     for (uint64_t k = m; k-- > 0;) {                 // col_bwt.hpp:510, i = m-1-k
         const uint64_t g = off + k;
-        const uint32_t c = win.pop();                // :512 pattern[m-i-1], raw byte
+        const uint32_t c = win.get(s_rd, g);         // :512 pattern[m-i-1], raw byte
         const uint32_t col_id = row_cid(w);          // :513 before any re-orientation
         if (row_char(w) == c) {                      // :516
             ++L;                                     // :517
@@ -217,10 +210,7 @@ __global__ __launch_bounds__(kQueryBlock) void pml_query_kernel(DevTable T, cons
             if ((g & (kFlush - 1)) == 0 || k == 0) acc.flush(pml, cid, g);
         }
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
-        if ((g & 15) == 0) {
-            if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
-            win.load(s_rd, g - 1);
-        }
+        if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
 
         // LF_table::LF (LF_table.hpp:251-262)
         uint32_t j = row_interval(w);                // :253

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""A/B timing of libcolbwt build variants on one GPU (experiment tool).
+
+    python tools/ab_bench.py [--rows N --reads N --read-len M --reps K] lib1.so lib2.so ...
+
+Each variant loads the same synthetic index, runs the query on the same
+device-resident reads (sampled once), interleaved `reps` times; prints one JSON
+line per variant with the HIP-event kernel time and a checksum of the outputs
+(all variants must agree).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("h2d_ms", C.c_double),
+                ("kernel_ms", C.c_double), ("d2h_ms", C.c_double), ("algorithmic_bytes", C.c_uint64)]
+
+
+def bind(path):
+    L = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    L.colbwt_last_error.restype = C.c_char_p
+    L.colbwt_index_open_memory.argtypes = [vp, u64, vp, i32, C.POINTER(vp)]
+    L.colbwt_query_device.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, C.POINTER(Stats)]
+    L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=200_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--sub-permille", type=int, default=10)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    import torch
+    pkg = load_package()
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(a.rows, 8, 0, 42)
+    n_reads, m = a.reads, a.read_len
+    nb = n_reads * m
+    d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    variants = []
+    for path in a.libs:
+        L = bind(os.path.abspath(path))
+        h = C.c_void_p()
+        rc = L.colbwt_index_open_memory(image.ctypes.data, image.size, None, 0, C.byref(h))
+        assert rc == 0, L.colbwt_last_error()
+        variants.append((os.path.basename(path), L, h, []))
+    name0, L0, h0, _ = variants[0]
+    assert L0.colbwt_synth_reads_device(h0, n_reads, m, a.sub_permille, 43, d_bases.data_ptr(), d_off.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    sums = {}
+    for rep in range(a.reps + 1):
+        for name, L, h, times in variants:
+            d_pml = torch.zeros(nb + 16, dtype=torch.int16, device=dev)
+            d_cid = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
+            st = Stats()
+            rc = L.colbwt_query_device(h, d_bases.data_ptr(), d_off.data_ptr(), n_reads, nb, d_pml.data_ptr(), 2,
+                                       d_cid.data_ptr(), None, C.byref(st))
+            assert rc == 0, L.colbwt_last_error()
+            if rep:
+                times.append(st.kernel_ms)
+            else:
+                sums[name] = (int(d_pml[:nb].to(torch.int64).sum().item()), int(d_cid[:nb].to(torch.int64).sum().item()))
+            del d_pml, d_cid
+    ref = sums[variants[0][0]]
+    for name, L, h, times in variants:
+        print(json.dumps({"lib": name, "ms": round(float(np.mean(times)), 3), "min_ms": round(min(times), 3),
+                          "Gbase_s": round(nb / np.mean(times) / 1e6, 3), "checksum_ok": sums[name] == ref,
+                          "rows": a.rows, "reads": n_reads, "read_len": m}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -3,12 +3,16 @@
 profiles/<tag>_kernel_stats.csv + profiles/<tag>_summary.json.
 
 HBM traffic per launch follows MI355X_MICROARCH.md (HBM / rocprofv3 PMC):
-FETCH_SIZE and WRITE_SIZE are collected in separate passes, are in KiB, and
-FETCH_SIZE = TCC_EA0_RDREQ x 64 B.  For THIS kernel's access pattern (random
-16-byte row loads: one 64-byte request each, cross-checked against
-TCC_EA0_RDREQ and against the known load count of tools/gather_bench) the
-reading is taken as exact, not doubled -- the x2 correction in the guide is
-for wide coalesced streams whose 128-byte requests are tallied at 64 bytes.
+FETCH_SIZE and WRITE_SIZE are collected in separate passes and are in KiB;
+on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B although every read request is a
+128-byte line fill, so the read side is DOUBLED (the guide's gfx950
+correction).  That the correction also holds for this kernel's pattern
+(random 16-byte row loads) was calibrated with tools/gather_bench
+(profiles/r01_gather_calibration.json): a known number of dependent random
+16-byte loads reads FETCH_SIZE = 64 B per load, and a second load in the
+other 64-byte half of the same 128-byte line adds NO read request, while one
+in the next line adds exactly one.  WRITE_SIZE is taken as is (32/64-byte
+write requests are tallied at their size).
 """
 import collections
 import csv
@@ -47,9 +51,9 @@ def main():
     for k, d in summary["kernels"].items():
         p = d.get("pmc_per_launch", {})
         if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
-            d["hbm_read_bytes_per_launch"] = p["FETCH_SIZE"] * 1024
+            d["hbm_read_bytes_per_launch"] = p["FETCH_SIZE"] * 1024 * 2   # 128-byte lines tallied at 64
             d["hbm_write_bytes_per_launch"] = p["WRITE_SIZE"] * 1024
-            d["hbm_bytes_per_launch"] = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+            d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
     bt = os.path.join(src, "bench_trace.json")
     if os.path.exists(bt):
         try:
