@@ -90,42 +90,29 @@ def main():
     d_cid = torch.zeros(n_bases + 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    # ---- gather destination on rank 0 (byte views; u16 PML travels as 2 bytes)
+    # ---- chunked query + gather pipeline (byte views; u16 PML travels as 2 bytes)
+    from colbwt_amd import multi_gpu
     n_chunks = args.chunks or (1 if world == 1 else 4)
-    bounds = [n_reads * c // n_chunks for c in range(n_chunks + 1)]
-    pml_bytes = d_pml.view(torch.uint8)
-    if world > 1 and rank == 0:
-        g_pml = torch.empty((world, 2 * n_bases), dtype=torch.uint8, device=dev)
-        g_cid = torch.empty((world, n_bases), dtype=torch.uint8, device=dev)
+    pml_bytes = d_pml.view(torch.uint8)[:2 * n_bases]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
+                                    [(pml_bytes, 2), (d_cid[:n_bases], 1)], dev, (stream, comm_stream))
     kernel_events = []
 
+    def query_chunk(lo, hi):
+        tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
+                         d_pml.data_ptr(), d_cid.data_ptr(), 2, stream.cuda_stream)
+
+    def timing_hook(when):      # HIP events on the stream the kernel is launched on
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        if when == "before":
+            kernel_events.append([e, None])
+        else:
+            kernel_events[-1][1] = e
+
     def step(record):
-        works = []
-        for c in range(n_chunks):
-            lo, hi = bounds[c], bounds[c + 1]
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
-                             d_pml.data_ptr(), d_cid.data_ptr(), 2, stream.cuda_stream)
-            if record:
-                e1.record(stream)
-                kernel_events.append((e0, e1))
-            if world > 1:
-                done = torch.cuda.Event()
-                done.record(stream)
-                with torch.cuda.stream(comm_stream):
-                    comm_stream.wait_event(done)
-                    for src, dst, scale in ((pml_bytes, g_pml if rank == 0 else None, 2),
-                                            (d_cid, g_cid if rank == 0 else None, 1)):
-                        piece = src[scale * lo * m: scale * hi * m]
-                        glist = [dst[r, scale * lo * m: scale * hi * m] for r in range(world)] if rank == 0 else None
-                        works.append(dist.gather(piece, glist, dst=0, async_op=True))
-        for w in works:
-            w.wait()
-        if comm_stream is not None:
-            stream.wait_stream(comm_stream)
+        pipe.step(query_chunk, timing_hook if record else None)
 
     def fence():
         if world > 1:

@@ -1,0 +1,91 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the same sharding and
+chunked gather pipeline bench.py uses on RCCL (col-bwt_amd/multi_gpu.py); the
+per-rank compute is the oracle here (the checker standing in for the GPU
+kernel, which cannot run in this tier), so the test pins the plumbing: shard
+boundaries, chunk byte ranges, gather order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_reads, m, n_chunks, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_oracle, load_package
+    pkg = load_package()
+    from colbwt_amd import multi_gpu
+    import helpers
+    oracle = load_oracle()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    image = pkg.synth_index(3000, mean_len=6, split_permille=100, seed=5).tobytes()
+    reads = helpers.backward_walk_reads(image, n_reads * world, m, 0.02, seed=9)     # the whole job
+    mine = reads[rank * n_reads:(rank + 1) * n_reads]                                 # this rank's shard
+    bases, off = helpers.concat_reads(mine)
+    ref = oracle.OracleIndex(image)
+    pml = torch.zeros(n_reads * m, dtype=torch.int16)
+    cid = torch.zeros(n_reads * m, dtype=torch.uint8)
+
+    def query_chunk(lo, hi):           # stand-in for ColPml.query_device on reads [lo, hi)
+        p, c = ref.query_batch(bases[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo])
+        pml[lo * m:hi * m] = torch.from_numpy(p.view(np.int16))
+        cid[lo * m:hi * m] = torch.from_numpy(c)
+
+    pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
+                                    [(pml.view(torch.uint8), 2), (cid, 1)], torch.device("cpu"))
+    pipe.step(query_chunk)
+    if rank == 0:
+        all_bases, all_off = helpers.concat_reads(reads)
+        ep, ec = ref.query_batch(all_bases, all_off)
+        gp = pipe.gathered[0].reshape(-1).numpy().view(np.uint16)
+        gc = pipe.gathered[1].reshape(-1).numpy()
+        q.put(bool(np.array_equal(gp, ep) and np.array_equal(gc, ec)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_chunks", [1, 3])
+def test_two_rank_gather_matches_single_rank(n_chunks):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 40, 50, n_chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True
+
+
+def test_shard_reads_balances_bases():
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    load_package()
+    from colbwt_amd import multi_gpu
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 500, size=1000)
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        sh = multi_gpu.shard_reads(off, world)
+        assert sh[0][0] == 0 and sh[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+        per = [int(off[hi] - off[lo]) for lo, hi in sh]
+        assert max(per) - min(per) <= 2 * 500
+    assert multi_gpu.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
+    assert multi_gpu.chunk_bounds(0, 4) == [0, 0]
