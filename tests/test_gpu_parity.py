@@ -254,3 +254,25 @@ def test_full_scale_properties(pkg, oracle):
     ref = oracle.OracleIndex(image)
     ep, ec = ref.query_batch(hb.reshape(-1), off, threads=16)
     assert np.array_equal(sp, ep) and np.array_equal(sc, ec)
+
+
+def test_cli_pml_query_and_col_bwt_launcher(golden_dir, tmp_path):
+    """The drop-in command lines: `pml_query -p <fa> <prefix>` (pml_query.cpp:92-143,
+    same getopt string) and `col-bwt query -p PATTERN index` (col-bwt.py:226-228)
+    reproduce the golden .pml/.cid bytes; a missing index is a non-zero exit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "col-bwt_amd", "pml_query")
+    launcher = os.path.join(root, "col-bwt_amd", "col-bwt")
+    for k, cmd in enumerate(([exe, "-v", "-p"], [sys.executable, launcher, "query", "-p"])):
+        d = tmp_path / f"run{k}"
+        d.mkdir()
+        fa = d / "kat_d.fa"
+        shutil.copy(os.path.join(golden_dir, "kat_d.fa"), fa)
+        out = subprocess.run(cmd + [str(fa), os.path.join(golden_dir, "kat_d")], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        for ext in (".pml", ".cid"):
+            assert open(str(fa) + ext, "rb").read() == open(os.path.join(golden_dir, "kat_d.fa" + ext), "rb").read()
+    bad = subprocess.run([exe, "-p", str(fa), "/nonexistent/prefix"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "[ERROR]" in bad.stderr
