@@ -173,7 +173,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         oracle = load_oracle()
         ref = oracle.OracleIndex(image)
-        cores = len(os.sched_getaffinity(0))
+        cores = min(len(os.sched_getaffinity(0)), 16)   # a 1-GPU box's CPU share is 16 cores
 
         def run_sample(k, threads):
             hb = d_bases[:k * m].cpu().numpy()
