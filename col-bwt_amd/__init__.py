@@ -23,7 +23,7 @@ EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
     "colbwt_query_device", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
-    "colbwt_synth_reads_device",
+    "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
 )
 
 
@@ -82,6 +82,8 @@ def lib():
     L.colbwt_synth_index_bytes.restype = u64
     L.colbwt_synth_index.argtypes = [u64, C.c_uint32, C.c_uint32, u64, vp, u64]
     L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
+    L.colbwt_build_col_pml.argtypes = [C.c_char_p, C.c_char_p]
+    L.colbwt_build_col_pml_arrays.argtypes = [vp, u64, vp, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(u64)]
     _lib = L
     return L
 
@@ -184,3 +186,29 @@ def synth_index(rows, mean_len=8, split_permille=0, seed=42):
     out = np.empty(nbytes, np.uint8)
     _check(lib().colbwt_synth_index(rows, mean_len, split_permille, seed, out.ctypes.data, nbytes))
     return out
+
+
+def build_col_pml(prefix, out_path=None):
+    """`build_col_bwt <prefix>` (src/build_col_bwt.cpp:38-52): writes <prefix>.col_pml."""
+    _check_build(lib().colbwt_build_col_pml(os.fsencode(prefix), os.fsencode(out_path) if out_path else None))
+
+
+def build_col_pml_arrays(heads, lens, col_ids, split_pos, thr_pos):
+    """col_pml(heads, lengths, col_ids, thresholds, splits) + serialize -> image bytes (uint8 array)."""
+    heads = np.ascontiguousarray(heads, np.uint8)
+    lens = np.ascontiguousarray(lens, np.uint64)
+    col_ids = np.ascontiguousarray(col_ids, np.uint8)
+    split_pos = np.ascontiguousarray(split_pos, np.uint64)
+    thr_pos = np.ascontiguousarray(thr_pos, np.uint64)
+    need = C.c_uint64(0)
+    args = [heads.ctypes.data, heads.size, lens.ctypes.data, col_ids.ctypes.data, col_ids.size,
+            split_pos.ctypes.data, split_pos.size, thr_pos.ctypes.data, thr_pos.size]
+    lib().colbwt_build_col_pml_arrays(*args, None, 0, C.byref(need))
+    out = np.zeros(need.value, np.uint8)
+    _check_build(lib().colbwt_build_col_pml_arrays(*args, out.ctypes.data, out.size, C.byref(need)))
+    return out
+
+
+def _check_build(rc):
+    if rc != 0:
+        raise ColbwtError(rc, "index construction failed (missing/short input file or bad argument)")

@@ -118,6 +118,22 @@ int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_
 int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path,
                       const char *cid_path, uint64_t batch_bases, colbwt_stats *stats);
 
+/* ---- index construction (SURVEY.md 8(f) "next" #1) ------------------------ */
+
+/* build_col_bwt <prefix> (src/build_col_bwt.cpp:14-52): reads <prefix>.bwt.heads,
+ * .bwt.len, .col_ids, .col_runs (plain sdsl::bit_vector as col_split writes it,
+ * col_split.hpp:384-386), .thr_pos and writes <prefix>.col_pml (or out_path)
+ * exactly as col_pml(heads, lengths, col_ids, thresholds, splits) + serialize
+ * would (col_bwt.hpp:124-230, 391-395, 440-457, 360-370).  Host code. */
+int colbwt_build_col_pml(const char *prefix, const char *out_path);
+/* Same over decoded arrays: split_pos = ascending positions of the set bits of
+ * .col_runs; lens / thr_pos already widened from 5 bytes.  *out_len receives
+ * the image size (also when out is NULL / too small, then ERR_ARG). */
+int colbwt_build_col_pml_arrays(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens,
+                                const uint8_t *col_ids, uint64_t n_ids, const uint64_t *split_pos,
+                                uint64_t n_splits, const uint64_t *thr_pos, uint64_t n_thr, void *out,
+                                uint64_t out_cap, uint64_t *out_len);
+
 /* ---- synthetic inputs (benchmark / test generators) ------ */
 
 /* Bytes needed for a synthetic .col_pml image of `rows` rows. */

@@ -417,3 +417,106 @@ int oracle_pml_query_files(const oracle_index *x, const char *pattern_path,
     free(seq);
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* Builder restatement.                        */
+/* ------------------------------------------------------------------ */
+typedef struct brow { uint8_t c; uint64_t idx, interval, offset, id, thr; } brow;
+
+static void put_le(uint8_t *p, uint64_t v, unsigned nbytes)
+{
+    for (unsigned b = 0; b < nbytes; ++b) p[b] = (uint8_t)(v >> (8u * b));
+}
+
+uint64_t oracle_build_col_pml(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens,
+                              const uint8_t *col_ids, uint64_t n_ids, const uint64_t *split_pos,
+                              uint64_t n_splits, const uint64_t *thr_pos, uint64_t n_thr,
+                              uint8_t *out, uint64_t out_cap)
+{
+    /* col_bwt(heads, lengths, col_ids, splits), col_bwt.hpp:124-230 */
+    uint64_t cap = n_heads + n_splits + 1, nrows = 0;
+    brow *rows = (brow *)calloc(cap, sizeof(brow));
+    uint64_t s_set_bits = n_splits;                               /* :141-142 */
+    uint64_t n = 0, bwt_r = 0, s = 0, id_pos = 0;                 /* :158-163 */
+    uint64_t s_curr = n_splits ? split_pos[0] : 0;                /* :165 s_select(s + 1) */
+    uint64_t curr_id = 0;                                         /* :166 */
+#define SELECT_NEXT() ((s < s_set_bits) ? split_pos[s] : 0)       /* s_select(s + 1), else 0 (:180,:198) */
+#define READ_ID() do { if (id_pos < n_ids) curr_id = col_ids[id_pos++]; } while (0) /* 1 byte into a zeroed size_t */
+    for (uint64_t h = 0; h < n_heads; ++h) {                      /* :167 while ((c = heads.get()) != EOF) */
+        signed char c = (signed char)heads[h];
+        if (c == (signed char)EOF) break;                         /* char 0xFF compares equal to EOF */
+        uint64_t length = lens[h];                                /* :169-170 */
+        if (c <= 1) c = 1;                                        /* :171 TERMINATOR; bytes >= 0x80 are negative chars */
+        uint64_t run_end = n + length;                            /* :176 */
+        if (s_curr == n) {                                        /* :177-181 */
+            READ_ID();
+            ++s;
+            s_curr = SELECT_NEXT();
+        }
+        while (s < s_set_bits && s_curr < run_end) {              /* :183 */
+            rows[nrows].c = (uint8_t)c; rows[nrows].idx = n; rows[nrows].id = curr_id; ++nrows;  /* :184-185 */
+            uint64_t delta = s_curr - n;                          /* :186 */
+            n += delta;                                           /* :187 */
+            length -= delta;                                      /* :188 */
+            ++s;                                                  /* :197 */
+            s_curr = SELECT_NEXT();                               /* :198 */
+            READ_ID();                                            /* :199 */
+        }
+        if (length > 0) {                                         /* :202 */
+            rows[nrows].c = (uint8_t)c; rows[nrows].idx = n; rows[nrows].id = curr_id; ++nrows;  /* :203-204 */
+            n += length;                                          /* :205 */
+        }
+        ++bwt_r;                                                  /* :214 */
+    }
+    uint64_t r = nrows;                                           /* :216 */
+#undef SELECT_NEXT
+#undef READ_ID
+
+    /* LF_table::compute_table, LF_table.hpp:365-387: L_block_indices[c] lists the rows
+     * holding c in row order; the outer loop runs over c ascending. */
+#define BLEN(i) (((i) == r - 1 ? n : rows[(i) + 1].idx) - rows[i].idx)  /* get_length :204-207 */
+    uint64_t curr_L_num = 0, L_seen = 0, F_seen = 0;              /* :366-368 */
+    for (unsigned cc = 0; cc < 256; ++cc) {                       /* :369 */
+        for (uint64_t pos = 0; pos < r; ++pos) {                  /* :371 (rows with char cc, ascending) */
+            if (rows[pos].c != cc) continue;
+            rows[pos].interval = curr_L_num & 0xFFFFFFFFull;      /* :375, RUN_BITS bit-field */
+            rows[pos].offset = (F_seen - L_seen) & 0xFFFFull;     /* :376, LEN_BITS bit-field */
+            F_seen += BLEN(pos);                                  /* :378 */
+            while (curr_L_num < r && F_seen >= L_seen + BLEN(curr_L_num)) {  /* :380 */
+                L_seen += BLEN(curr_L_num);                       /* :382 */
+                ++curr_L_num;                                     /* :383 */
+            }
+        }
+    }
+#undef BLEN
+
+    /* col_pml::read_thresholds, col_bwt.hpp:440-457 */
+    {
+        uint64_t i = 0;
+        for (uint64_t k = 0; k < n_thr && i < r; ++k) {           /* :446 while (thresholds.read(...)) */
+            uint8_t last = rows[i].c;                             /* :448 */
+            do {
+                rows[i++].thr = thr_pos[k] & 0xFFFFFFFFFFull;     /* :450, BWT_BITS bit-field */
+            } while (i < r && rows[i].c == last);                 /* :451 */
+        }
+    }
+
+    /* col_bwt::serialize + LF_table::serialize (col_bwt.hpp:360-370, LF_table.hpp:325-342) */
+    uint64_t need = ORACLE_HEADER_BYTES + r * (uint64_t)ORACLE_ROW_BYTES;
+    if (need > out_cap) { free(rows); return 0; }
+    put_le(out + 0, bwt_r, 8);
+    put_le(out + 8, n, 8);
+    put_le(out + 16, r, 8);
+    put_le(out + 24, r, 8);
+    for (uint64_t i = 0; i < r; ++i) {
+        uint8_t *p = out + ORACLE_HEADER_BYTES + i * ORACLE_ROW_BYTES;
+        p[0] = rows[i].c;
+        put_le(p + 1, rows[i].idx & 0xFFFFFFFFFFull, 5);
+        put_le(p + 6, rows[i].interval, 4);
+        put_le(p + 10, rows[i].offset, 2);
+        p[12] = (uint8_t)rows[i].id;                              /* col_row ctor :47-52: ids < 256 unchanged */
+        put_le(p + 13, rows[i].thr, 5);
+    }
+    free(rows);
+    return need;
+}

@@ -91,6 +91,26 @@ int oracle_write_text(void *file, const char *name, const uint64_t *vals, uint64
 int oracle_pml_query_files(const oracle_index *x, const char *pattern_path,
                            const char *pml_path, const char *cid_path);
 
+
+/* ------------------------------------------------------------------------
+ * SURVEY.md 8(f) "next" #1: the in-repo index builder, build_col_bwt
+ * (src/build_col_bwt.cpp:38-52): col_pml(heads, lengths, col_ids, thresholds,
+ * splits) = col_bwt ctor (col_bwt.hpp:124-230) + LF_table::compute_table
+ * (LF_table.hpp:365-387) + col_pml::read_thresholds (col_bwt.hpp:440-457) +
+ * col_bwt::serialize (col_bwt.hpp:360-370).  Inputs are the decoded streams:
+ *   heads[n_heads]          .bwt.heads bytes (col_bwt.hpp:167)
+ *   lens[n_heads]           .bwt.len 5-byte values, already widened (:170)
+ *   col_ids[n_ids]          .col_ids bytes (:178,:199)
+ *   split_pos[n_splits]     positions of the set bits of .col_runs, ascending
+ *                           (what s_select(k) returns, :165,:180,:198)
+ *   thr_pos[n_thr]          .thr_pos 5-byte values, widened (:446)
+ * Writes the .col_pml image into out (capacity out_cap); returns its length,
+ * or 0 when out_cap is too small.  Parity: pinned by the Appendix D KAT (its
+ * 302-byte index was written by this reference constructor). */
+uint64_t oracle_build_col_pml(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens,
+                              const uint8_t *col_ids, uint64_t n_ids, const uint64_t *split_pos,
+                              uint64_t n_splits, const uint64_t *thr_pos, uint64_t n_thr,
+                              uint8_t *out, uint64_t out_cap);
 #ifdef __cplusplus
 }
 #endif

@@ -115,3 +115,22 @@ class OracleIndex:
             self.close()
         except Exception:
             pass
+
+
+def build_col_pml(heads, lens, col_ids, split_pos, thr_pos):
+    """Reference constructor restatement (col_bwt.hpp:124-230 etc.) -> image bytes."""
+    L = lib()
+    L.oracle_build_col_pml.restype = C.c_uint64
+    L.oracle_build_col_pml.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                       C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    heads = np.ascontiguousarray(heads, np.uint8)
+    lens = np.ascontiguousarray(lens, np.uint64)
+    col_ids = np.ascontiguousarray(col_ids, np.uint8)
+    split_pos = np.ascontiguousarray(split_pos, np.uint64)
+    thr_pos = np.ascontiguousarray(thr_pos, np.uint64)
+    cap = 32 + 18 * (heads.size + split_pos.size + 1)
+    out = np.zeros(cap, np.uint8)
+    n = L.oracle_build_col_pml(heads.ctypes.data, heads.size, lens.ctypes.data, col_ids.ctypes.data, col_ids.size,
+                               split_pos.ctypes.data, split_pos.size, thr_pos.ctypes.data, thr_pos.size,
+                               out.ctypes.data, cap)
+    return out[:n].copy()
