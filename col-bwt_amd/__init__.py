@@ -22,7 +22,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "colbwt.h")
 EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
-    "colbwt_query_device", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
+    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
 )
 
@@ -77,6 +77,7 @@ def lib():
     L.colbwt_query_batch.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(Stats)]
     L.colbwt_query_batch_u32.argtypes = [vp, vp, vp, u64, vp, vp, C.POINTER(Stats)]
     L.colbwt_query_device.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, C.POINTER(Stats)]
+    L.colbwt_query_device_ordered.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, vp, C.POINTER(Stats)]
     L.colbwt_query_file.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.POINTER(Stats)]
     L.colbwt_synth_index_bytes.argtypes = [u64]
     L.colbwt_synth_index_bytes.restype = u64
@@ -148,11 +149,13 @@ class ColPml:
         return pml, cid, st
 
     def query_device(self, d_bases, d_read_off, n_reads, n_bases, d_pml, d_cid, pml_bytes=2,
-                     stream=0, timed=False):
-        """Device-resident entry point: arguments are raw device pointers (ints)."""
+                     stream=0, timed=False, d_order=None):
+        """Device-resident entry point: arguments are raw device pointers (ints).
+        d_order: optional device array of read indices by decreasing length."""
         st = Stats()
-        _check(lib().colbwt_query_device(self._h, d_bases, d_read_off, n_reads, n_bases, d_pml,
-                                         pml_bytes, d_cid, stream, C.byref(st) if timed else None))
+        _check(lib().colbwt_query_device_ordered(self._h, d_bases, d_read_off, n_reads, n_bases, d_pml,
+                                                 pml_bytes, d_cid, d_order, stream,
+                                                 C.byref(st) if timed else None))
         return st
 
     # -- pml_query main, vec mode (pml_query.cpp:92-143) ----------------------

@@ -78,10 +78,11 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     if (n_reads == 0) return COLBWT_OK;
     if (!read_off) return fail(COLBWT_ERR_ARG, "null read_off");
     if (read_off[0] != 0) return fail(COLBWT_ERR_ARG, "read_off[0] must be 0");
-    uint64_t max_len = 0;
+    uint64_t max_len = 0, min_len = ~0ull;
     for (uint64_t k = 0; k < n_reads; ++k) {
         if (read_off[k + 1] < read_off[k]) return fail(COLBWT_ERR_ARG, "read_off not non-decreasing");
         max_len = std::max(max_len, read_off[k + 1] - read_off[k]);
+        min_len = std::min(min_len, read_off[k + 1] - read_off[k]);
     }
     const uint64_t n_bases = read_off[n_reads];
     if (sizeof(PmlT) == 2 && max_len > 65535)
@@ -100,7 +101,22 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint8_t *d_bases = nullptr, *d_cid = nullptr;
     uint64_t *d_off = nullptr;
+    uint32_t *d_order = nullptr;
     PmlT *d_pml = nullptr;
+    // Ragged batch: assign lanes by decreasing read length (counting sort over 256 length
+    // classes is enough: waves only need reads of SIMILAR length side by side).
+    std::vector<uint32_t> order;
+    if (n_reads <= 0xFFFFFFFFull && n_reads > 64 && max_len > min_len + (min_len >> 2) + 16) {
+        const uint64_t span = max_len - min_len + 1;
+        uint32_t shift = 0;
+        while ((span >> shift) > 4096) ++shift;
+        std::vector<uint64_t> start((span >> shift) + 2, 0);
+        for (uint64_t k = 0; k < n_reads; ++k) ++start[((max_len - (read_off[k + 1] - read_off[k])) >> shift) + 1];
+        for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+        order.resize(n_reads);
+        for (uint64_t k = 0; k < n_reads; ++k)
+            order[start[(max_len - (read_off[k + 1] - read_off[k])) >> shift]++] = (uint32_t)k;
+    }
     const uint64_t bases_alloc = (n_bases + 64 + 63) & ~63ull;  // the kernel reads whole 64-byte blocks
     float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
 
@@ -115,8 +131,12 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     API_HIP(hipMemsetAsync(d_bases + (bases_alloc - 128), 0, 128, stream));
     API_HIP(hipMemcpyAsync(d_bases, bases, n_bases, hipMemcpyHostToDevice, stream));
     API_HIP(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (!order.empty()) {
+        API_HIP(hipMalloc((void **)&d_order, n_reads * sizeof(uint32_t)));
+        API_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    }
     API_HIP(hipEventRecord(ev[1], stream));
-    launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, stream);
+    launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     API_HIP(hipGetLastError());
     API_HIP(hipEventRecord(ev[2], stream));
     API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
@@ -138,6 +158,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
 done:
     if (d_bases) (void)hipFree(d_bases);
     if (d_off) (void)hipFree(d_off);
+    if (d_order) (void)hipFree(d_order);
     if (d_pml) (void)hipFree(d_pml);
     if (d_cid) (void)hipFree(d_cid);
     for (auto &e : ev)
@@ -214,6 +235,13 @@ int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64
 int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                         uint64_t n_bases, void *d_pml, int pml_bytes, uint8_t *d_cid, void *hip_stream,
                         colbwt_stats *stats) {
+    return colbwt_query_device_ordered(idx, d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, nullptr,
+                                       hip_stream, stats);
+}
+
+int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off,
+                                uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes, uint8_t *d_cid,
+                                const uint32_t *d_order, void *hip_stream, colbwt_stats *stats) {
     if (!idx) return fail(COLBWT_ERR_ARG, "null index");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (pml_bytes != 2 && pml_bytes != 4) return fail(COLBWT_ERR_ARG, "pml_bytes must be 2 or 4");
@@ -231,7 +259,7 @@ int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_
         API_HIP(hipEventCreate(&e1));
         API_HIP(hipEventRecord(e0, stream));
     }
-    launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, stream);
+    launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     API_HIP(hipGetLastError());
     if (stats) {
         API_HIP(hipEventRecord(e1, stream));

@@ -10,8 +10,10 @@ namespace colbwt {
 constexpr uint32_t kQueryBlock = 256;  // 4 waves; one lane per read
 
 // col_pml::query_pml for n_reads reads resident in HBM (col_bwt.hpp:498-529).
+// d_order (nullable): read indices by decreasing length (lane assignment for ragged batches).
 void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t *d_read_off,
-                      uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream);
+                      uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order,
+                      hipStream_t stream);
 
 // ---- load-time kernels (index_kernels.hip) --------------------------------
 struct RelayoutReport {

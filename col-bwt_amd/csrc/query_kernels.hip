@@ -169,15 +169,19 @@ __global__ __launch_bounds__(kQueryBlock) __attribute__((amdgpu_num_sgpr(80), am
 void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
                                                                 const uint64_t *__restrict__ read_off,
                                                                 uint64_t n_reads, PmlT *__restrict__ pml,
-                                                                uint8_t *__restrict__ cid) {
+                                                                uint8_t *__restrict__ cid,
+                                                                const uint32_t *__restrict__ order) {
     constexpr bool kWide = sizeof(PmlT) == 4;
     __shared__ uint32_t s_rd[16][kQueryBlock];
     __shared__ uint8_t s_cmap[256];
     for (uint32_t t = threadIdx.x; t < 256; t += kQueryBlock) s_cmap[t] = T.cmap[t];
     __syncthreads();
 
-    const uint64_t rd = (uint64_t)blockIdx.x * kQueryBlock + threadIdx.x;
-    if (rd >= n_reads) return;
+    const uint64_t slot = (uint64_t)blockIdx.x * kQueryBlock + threadIdx.x;
+    if (slot >= n_reads) return;
+    // ragged batches: `order` lists the reads by decreasing length, so the 64 lanes of a
+    // wave walk reads of similar length and the longest reads start first
+    const uint64_t rd = order ? order[slot] : slot;
     const uint64_t off = read_off[rd];
     const uint64_t m = read_off[rd + 1] - off;
     if (m == 0) return;
@@ -229,16 +233,17 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
 }
 
 void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t *d_read_off,
-                      uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream) {
+                      uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order,
+                      hipStream_t stream) {
     if (n_reads == 0) return;
     const uint64_t blocks = (n_reads + kQueryBlock - 1) / kQueryBlock;
     dim3 grid((uint32_t)blocks), block(kQueryBlock);
     if (pml_bytes == 2)
         hipLaunchKernelGGL(pml_query_kernel<uint16_t>, grid, block, 0, stream, T, d_bases, d_read_off, n_reads,
-                           (uint16_t *)d_pml, d_cid);
+                           (uint16_t *)d_pml, d_cid, d_order);
     else
         hipLaunchKernelGGL(pml_query_kernel<uint32_t>, grid, block, 0, stream, T, d_bases, d_read_off, n_reads,
-                           (uint32_t *)d_pml, d_cid);
+                           (uint32_t *)d_pml, d_cid, d_order);
 }
 
 }  // namespace colbwt

@@ -110,6 +110,16 @@ int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_
                         uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes,
                         uint8_t *d_cid, void *hip_stream, colbwt_stats *stats);
 
+/* Same with an explicit lane assignment for ragged batches: d_order (device,
+ * n_reads entries, nullable) lists the read indices by decreasing length, so the
+ * 64 lanes of a wave walk reads of similar length.  Results are identical with
+ * or without it (each read's values only depend on that read); the host entry
+ * points build the order themselves when a batch is ragged. */
+int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off,
+                                uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes,
+                                uint8_t *d_cid, const uint32_t *d_order, void *hip_stream,
+                                colbwt_stats *stats);
+
 /* pml_query in vec mode (pml_query.cpp:92-143): reads FASTA/FASTQ (optionally
  * gzip) from pattern_path, writes text pml_path / cid_path (NULL => pattern +
  * ".pml" / ".cid", pml_query.cpp:124-125) in the byte format of pml_to_vec
