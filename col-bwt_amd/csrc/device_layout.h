@@ -12,7 +12,8 @@
 //                                          0xFFFF = "long": idx[j+1]-idx[j]
 //       .z  idx low 32 bits                      LF_row::idx
 //       .w  idx high 8 | char << 8 | col_id << 16 | hints << 24
-//     hints (when sigma <= 5): 2 bits per other character c, precomputed at
+//     hints: 2 bits for each of the 4 most frequent OTHER characters c (dense
+//     character indices are ordered by frequency), precomputed at
 //     load: how `pos < threshold(succ_c(row))` (col_bwt.hpp:560) comes out for
 //     EVERY offset inside the row -- kHintPred (always true, or no successor),
 //     kHintSucc (always false) or kHintCompare (the threshold falls inside the
@@ -40,7 +41,8 @@ constexpr uint32_t kAbsent = 0xFFu;         // cmap: byte not in the BWT
 constexpr uint32_t kAlgBytesPerBase = 27;
 constexpr uint32_t kHintPred = 0, kHintSucc = 1, kHintCompare = 2;
 constexpr uint32_t kHintAllCompare = 0xAAu; // every slot = kHintCompare
-constexpr uint32_t kHintMaxSigma = 5;
+constexpr uint32_t kHintSlots = 4;          // 2 bits each in the row's spare byte
+constexpr uint32_t kHintMaxSigma = 5;       // characters that can own a slot: the 5 most frequent
 
 struct DevTable {
     const uint4 *rows;        // r + 1
@@ -52,7 +54,7 @@ struct DevTable {
     uint32_t r;
     uint32_t sigma;
     uint32_t nblk;
-    uint32_t use_hints;       // 1 when the per-row threshold hints are valid
+    uint32_t use_hints;       // 1 once hint_kernel has run (always, after load)
 };
 
 }  // namespace colbwt

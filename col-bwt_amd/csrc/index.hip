@@ -140,11 +140,19 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err
     }
 
     // ---- character map: byte -> dense index over the characters present
+    // (ordered by decreasing row count so the hint slots cover the frequent characters)
     uint8_t cmap[256];
     uint32_t sigma = 0;
-    for (uint32_t c = 0; c < 256; ++c) {
-        const bool present = (h_report.present[c >> 5] >> (c & 31)) & 1u;
-        cmap[c] = present ? (uint8_t)sigma++ : (uint8_t)kAbsent;
+    {
+        std::vector<uint32_t> chars;
+        for (uint32_t c = 0; c < 256; ++c) {
+            cmap[c] = (uint8_t)kAbsent;
+            if ((h_report.present[c >> 5] >> (c & 31)) & 1u) chars.push_back(c);
+        }
+        std::stable_sort(chars.begin(), chars.end(),
+                         [&](uint32_t a, uint32_t b) { return h_report.count[a] > h_report.count[b]; });
+        sigma = (uint32_t)chars.size();
+        for (uint32_t k = 0; k < sigma && k < 255; ++k) cmap[chars[k]] = (uint8_t)k;
     }
     if (sigma > 255) {  // 256 distinct bytes: index 255 would collide with kAbsent
         err = "all 256 byte values occur in the BWT; not supported";
@@ -196,11 +204,11 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err
     tbl_.nblk = nblk;
     tbl_.use_hints = 0;
 
-    // ---- per-row threshold hints (only representable for sigma <= 5)
-    if (sigma <= kHintMaxSigma) {
+    // ---- per-row threshold hints for the (up to) 5 most frequent characters
+    {
         HintChars hc{};
         for (uint32_t c = 0; c < 256; ++c)
-            if (cmap[c] != kAbsent) hc.c[cmap[c]] = (uint8_t)c;
+            if (cmap[c] != kAbsent && cmap[c] < 8) hc.c[cmap[c]] = (uint8_t)c;
         launch_hints(tbl_, (uint4 *)d_rows_, hc, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(0));

@@ -31,9 +31,11 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
                                                                   RelayoutReport *report) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t s_present[8];
+    __shared__ uint32_t s_count[256];
     __shared__ uint32_t s_flags, s_bad;
     const uint64_t blk_row = (uint64_t)blockIdx.x * kRelayoutBlock;  // relative to row0
     if (threadIdx.x < 8) s_present[threadIdx.x] = 0;
+    for (uint32_t t = threadIdx.x; t < 256; t += kRelayoutBlock) s_count[t] = 0;
     if (threadIdx.x == 0) { s_flags = 0; s_bad = kNone; }
 
     const uint64_t rows_here = (count - blk_row) < kRelayoutBlock ? (count - blk_row) : kRelayoutBlock;
@@ -71,9 +73,12 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         thr[i] = threshold;
         if (i + 1 == r) rows[r] = make_uint4(0, 0, (uint32_t)n, (uint32_t)(n >> 32));  // sentinel: idx = n
         atomicOr(&s_present[ch >> 5], 1u << (ch & 31));
+        atomicAdd(&s_count[ch], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 8 && s_present[threadIdx.x]) atomicOr(&report->present[threadIdx.x], s_present[threadIdx.x]);
+    for (uint32_t t = threadIdx.x; t < 256; t += kRelayoutBlock)
+        if (s_count[t]) atomicAdd(&report->count[t], s_count[t]);
     if (threadIdx.x == 0 && s_flags) {
         atomicOr(&report->flags, s_flags);
         atomicMin(&report->first_bad, s_bad);
@@ -128,14 +133,17 @@ __global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, H
     const uint32_t aidx = T.cmap[row_char(w)];
     const uint64_t lo = row_idx(w);
     const uint64_t hi = lo + row_len(T, i, w) - 1;
-    uint32_t hints = 0;
-    for (uint32_t cidx = 0; cidx < T.sigma; ++cidx) {
-        if (cidx == aidx) continue;
+    uint32_t hints = kHintAllCompare;
+    // dense indices are ordered by character frequency: the 4 hint slots of a row go to the
+    // 4 most frequent OTHER characters (cidx <= 4); rarer ones compare at query time
+    const uint32_t top = T.sigma < kHintMaxSigma ? T.sigma : kHintMaxSigma;
+    for (uint32_t cidx = 0; cidx < top; ++cidx) {
+        if (cidx == aidx || hint_slot(cidx, aidx) >= kHintSlots) continue;
         uint4 t;
         const uint32_t s = succ_char(T, i, chars.c[cidx], cidx, t);
         const uint64_t thr = (s != kNone) ? T.thr[s] : T.n;   // :535 thr = n when there is no successor
         const uint32_t code = hi < thr ? kHintPred : (lo >= thr ? kHintSucc : kHintCompare);
-        hints |= code << (2 * hint_slot(cidx, aidx));
+        hints = (hints & ~(3u << (2 * hint_slot(cidx, aidx)))) | (code << (2 * hint_slot(cidx, aidx)));
     }
     rows_rw[i].w = (w.w & 0x00FFFFFFu) | (hints << 24);
 }

@@ -20,6 +20,7 @@ struct RelayoutReport {
     uint32_t flags;      // bit0 idx not strictly increasing, bit1 interval >= r, bit2 idx >= n, bit3 idx[0] != 0
     uint32_t first_bad;  // smallest offending row
     uint32_t present[8]; // 256-bit set of characters seen
+    uint32_t count[256]; // rows per character (orders the dense character indices by frequency)
 };
 
 // Packed 18-byte rows [row0, row0+count) (plus the following row's idx when it

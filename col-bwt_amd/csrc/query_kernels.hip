@@ -42,7 +42,8 @@ __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t 
     const uint32_t cidx = s_cmap[c];
     if (cidx == kAbsent) return;  // c occurs nowhere: (interval, offset) unchanged (:533-534)
     uint32_t hint = kHintCompare;
-    if (T.use_hints) hint = (row_hints(w) >> (2 * hint_slot(cidx, s_cmap[row_char(w)]))) & 3u;
+    const uint32_t slot = hint_slot(cidx, s_cmap[row_char(w)]);
+    if (slot < kHintSlots) hint = (row_hints(w) >> (2 * slot)) & 3u;   // rarer characters: compare
     uint4 t;
     if (hint == kHintPred) {
         // pos < thr for every offset of this row (or no successor, thr = n :535): pred wins if it exists

@@ -89,6 +89,9 @@ static inline unsigned long long __ballot(int pred) {
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o | v; return o;
 }
+static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o + v; return o;
+}
 static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; if (v < o) *p = v; return o;
 }
