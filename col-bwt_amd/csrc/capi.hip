@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/colbwt.h"
@@ -327,12 +328,11 @@ int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *p
             rc = colbwt_query_batch(idx, bases.data(), off.data(), n_reads, pml16.data(), cid.data(), &st);
         }
         if (rc != COLBWT_OK) return rc;
-        for (uint64_t k = 0; k < n_reads; ++k) {  // pml_query.cpp:78-85
-            const uint64_t b = off[k], m = off[k + 1] - b;
-            if (wide) wp.record(names[k], pml32.data() + b, m);
-            else wp.record(names[k], pml16.data() + b, m);
-            wc.record(names[k], cid.data() + b, m);
-        }
+        // pml_query.cpp:78-85, formatted by several host threads (same bytes, same order)
+        const unsigned fmt_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (wide) wp.batch(names, off.data(), pml32.data(), n_reads, fmt_threads);
+        else wp.batch(names, off.data(), pml16.data(), n_reads, fmt_threads);
+        wc.batch(names, off.data(), cid.data(), n_reads, fmt_threads);
         if (stats) {
             stats->n_reads += st.n_reads;
             stats->n_bases += st.n_bases;

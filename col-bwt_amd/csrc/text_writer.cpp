@@ -3,6 +3,8 @@
 
 #include <string.h>
 
+#include <thread>
+
 namespace colbwt {
 
 namespace {
@@ -59,6 +61,64 @@ bool TextWriter::record(const std::string &name, const T *vals, uint64_t m) {
     buf_[used_++] = '\n';
     return ok_;
 }
+
+template <typename T>
+bool TextWriter::batch(const std::vector<std::string> &names, const uint64_t *off, const T *vals, uint64_t n_reads,
+                       unsigned threads) {
+    if (!f_) return false;
+    if (n_reads == 0) return ok_;
+    const uint64_t total = off[n_reads] - off[0];
+    if (threads < 1) threads = 1;
+    if (threads > n_reads) threads = (unsigned)n_reads;
+    if (total < (1u << 20)) threads = 1;
+    std::vector<std::vector<char>> out(threads);
+    std::vector<uint64_t> cut(threads + 1, n_reads);
+    cut[0] = 0;
+    for (unsigned t = 1, k = 0; t < threads; ++t) {  // contiguous shards balanced by base count
+        const uint64_t target = off[0] + total * t / threads;
+        uint64_t lo = cut[t - 1];
+        (void)k;
+        while (lo < n_reads && off[lo] < target) ++lo;
+        cut[t] = lo;
+    }
+    auto work = [&](unsigned t) {
+        std::vector<char> &b = out[t];
+        uint64_t need = 0;
+        for (uint64_t k = cut[t]; k < cut[t + 1]; ++k) need += names[k].size() + 4;
+        need += (off[cut[t + 1]] - off[cut[t]]) * (sizeof(T) == 1 ? 4 : 6) + 64;
+        b.resize(need);
+        size_t u = 0;
+        for (uint64_t k = cut[t]; k < cut[t + 1]; ++k) {
+            b[u++] = '>';
+            memcpy(&b[u], names[k].data(), names[k].size());
+            u += names[k].size();
+            b[u++] = ' ';
+            b[u++] = '\n';
+            if (u + (off[k + 1] - off[k]) * 11 + 2 > b.size()) b.resize(u + (off[k + 1] - off[k]) * 11 + 64 + b.size() / 2);
+            for (uint64_t e = off[k]; e < off[k + 1]; ++e) u += put_value(&b[u], (uint32_t)vals[e]);
+            b[u++] = '\n';
+        }
+        b.resize(u);
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < threads; ++t) ts.emplace_back(work, t);
+        for (auto &th : ts) th.join();
+    }
+    flush_();
+    for (unsigned t = 0; t < threads; ++t)
+        if (!out[t].empty()) ok_ = ok_ && fwrite(out[t].data(), 1, out[t].size(), f_) == out[t].size();
+    return ok_;
+}
+
+template bool TextWriter::batch<uint8_t>(const std::vector<std::string> &, const uint64_t *, const uint8_t *, uint64_t,
+                                         unsigned);
+template bool TextWriter::batch<uint16_t>(const std::vector<std::string> &, const uint64_t *, const uint16_t *, uint64_t,
+                                          unsigned);
+template bool TextWriter::batch<uint32_t>(const std::vector<std::string> &, const uint64_t *, const uint32_t *, uint64_t,
+                                          unsigned);
 
 template bool TextWriter::record<uint8_t>(const std::string &, const uint8_t *, uint64_t);
 template bool TextWriter::record<uint16_t>(const std::string &, const uint16_t *, uint64_t);

@@ -21,6 +21,13 @@ public:
     bool open(const std::string &path);
     template <typename T>
     bool record(const std::string &name, const T *vals, uint64_t m);
+    // The same bytes as calling record() for reads 0..n_reads-1 in order (read k =
+    // vals[off[k] .. off[k+1])), formatted by `threads` host threads.  The decimal
+    // formatting of ~3-4 bytes per base dominates the reference's query time on
+    // match-heavy reads.
+    template <typename T>
+    bool batch(const std::vector<std::string> &names, const uint64_t *off, const T *vals, uint64_t n_reads,
+               unsigned threads);
     bool close();
 
 private:

@@ -276,3 +276,47 @@ def test_cli_pml_query_and_col_bwt_launcher(golden_dir, tmp_path):
             assert open(str(fa) + ext, "rb").read() == open(os.path.join(golden_dir, "kat_d.fa" + ext), "rb").read()
     bad = subprocess.run([exe, "-p", str(fa), "/nonexistent/prefix"], capture_output=True, text=True)
     assert bad.returncode != 0 and "[ERROR]" in bad.stderr
+
+
+def test_large_file_parallel_text_formatting(pkg, oracle, tmp_path):
+    """A FASTA big enough for the multi-threaded formatter (> 1 MiB of values)
+    and for several GPU batches: still byte-identical to the sequential
+    reference format (pml_query.cpp:78-85)."""
+    rng = np.random.default_rng(61)
+    image = pkg.synth_index(200_000, mean_len=8, split_permille=50, seed=62)
+    reads = helpers.backward_walk_reads(image.tobytes(), 12_000, 150, 0.01, seed=63) + _rand_reads(rng, 3_000, 0, 400)
+    fa = tmp_path / "big.fa"
+    helpers.write_fasta(fa, reads, width=70)
+    tbl = pkg.ColPml.from_bytes(image)
+    st = tbl.query_file(str(fa), batch_bases=900_000)
+    assert st.n_reads == len(reads)
+    oracle.OracleIndex(image.tobytes()).pml_query_files(str(fa), str(fa) + ".opml", str(fa) + ".ocid")
+    assert open(str(fa) + ".pml", "rb").read() == open(str(fa) + ".opml", "rb").read()
+    assert open(str(fa) + ".cid", "rb").read() == open(str(fa) + ".ocid", "rb").read()
+
+
+def test_concurrent_host_threads_share_one_index(pkg, oracle):
+    """The C-ABI promises thread-safety on distinct batches (include/colbwt.h):
+    four host threads query one index at once; every result equals the oracle's."""
+    import threading
+    image = pkg.synth_index(300_000, mean_len=8, split_permille=0, seed=71)
+    tbl = pkg.ColPml.from_bytes(image)
+    ref = oracle.OracleIndex(image.tobytes())
+    jobs = []
+    for t in range(4):
+        reads = helpers.backward_walk_reads(image.tobytes(), 3000, 100 + 10 * t, 0.02, seed=80 + t)
+        jobs.append(helpers.concat_reads(reads))
+    results = [None] * 4
+
+    def run(t):
+        for _ in range(3):
+            results[t] = tbl.query_batch(*jobs[t])[:2]
+
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for t in range(4):
+        ep, ec = ref.query_batch(*jobs[t], threads=8)
+        assert np.array_equal(results[t][0], ep) and np.array_equal(results[t][1], ec)
