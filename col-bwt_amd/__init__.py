@@ -21,6 +21,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "colbwt.h")
 # every symbol include/colbwt.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
+    "colbwt_index_open_layout", "colbwt_index_open_memory_layout",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
     "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
@@ -35,7 +36,8 @@ class ColbwtError(RuntimeError):
 
 class Info(C.Structure):
     _fields_ = [("bwt_r", C.c_uint64), ("n", C.c_uint64), ("r", C.c_uint64), ("sigma", C.c_uint32),
-                ("device", C.c_uint32), ("device_bytes", C.c_uint64)]
+                ("device", C.c_uint32), ("device_bytes", C.c_uint64), ("layout", C.c_uint32),
+                ("reserved_", C.c_uint32), ("table_rows", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -71,6 +73,8 @@ def lib():
     L.colbwt_last_error.restype = C.c_char_p
     L.colbwt_index_open.argtypes = [C.c_char_p, vp, i32, C.POINTER(vp)]
     L.colbwt_index_open_memory.argtypes = [vp, u64, vp, i32, C.POINTER(vp)]
+    L.colbwt_index_open_layout.argtypes = [C.c_char_p, vp, i32, i32, C.POINTER(vp)]
+    L.colbwt_index_open_memory_layout.argtypes = [vp, u64, vp, i32, i32, C.POINTER(vp)]
     L.colbwt_index_close.argtypes = [vp]
     L.colbwt_index_close.restype = None
     L.colbwt_index_info.argtypes = [vp, C.POINTER(Info)]
@@ -109,16 +113,19 @@ class ColPml:
         self._h = handle
 
     @classmethod
-    def load(cls, prefix_or_file, device=0):
+    def load(cls, prefix_or_file, device=0, layout=0):
+        """layout: 0 = engine default, 1 = one-step rows, 2 = two-step rows (same results)."""
         h = C.c_void_p()
-        _check(lib().colbwt_index_open(os.fsencode(prefix_or_file), None, int(device), C.byref(h)))
+        _check(lib().colbwt_index_open_layout(os.fsencode(prefix_or_file), None, int(device), int(layout),
+                                              C.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_bytes(cls, image, device=0):
+    def from_bytes(cls, image, device=0, layout=0):
         arr = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8))
         h = C.c_void_p()
-        _check(lib().colbwt_index_open_memory(arr.ctypes.data, arr.size, None, int(device), C.byref(h)))
+        _check(lib().colbwt_index_open_memory_layout(arr.ctypes.data, arr.size, None, int(device), int(layout),
+                                                     C.byref(h)))
         return cls(h)
 
     def info(self):

@@ -4,6 +4,7 @@
 // computes PML/col-ids needs a HIP device and says so when there is none.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -21,6 +22,8 @@
 #include "text_writer.h"
 
 using namespace colbwt;
+
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_ONE_STEP
 
 struct colbwt_index {
     Index ix;
@@ -137,7 +140,10 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         API_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     API_HIP(hipEventRecord(ev[1], stream));
-    launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    if (idx->ix.layout() == 2)
+        launch_s2_query(idx->ix.table2(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    else
+        launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     API_HIP(hipGetLastError());
     API_HIP(hipEventRecord(ev[2], stream));
     API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
@@ -176,16 +182,29 @@ const char *colbwt_version(void) { return "colbwt-mi355x 0.1.0 (gfx950)"; }
 
 const char *colbwt_last_error(void) { return g_err.c_str(); }
 
+static int default_layout() {
+    const char *e = getenv("COLBWT_LAYOUT");   // experiment override: 1 = one-step, 2 = two-step
+    if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) return e[0] - '0';
+    return COLBWT_LAYOUT_DEFAULT_CHOICE;
+}
+
 int colbwt_index_open_memory(const void *bytes, uint64_t len, const colbwt_widths *widths, int device,
                              colbwt_index **out) {
+    return colbwt_index_open_memory_layout(bytes, len, widths, device, COLBWT_LAYOUT_AUTO, out);
+}
+
+int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbwt_widths *widths, int device,
+                                    int layout, colbwt_index **out) {
     if (!out) return fail(COLBWT_ERR_ARG, "null out");
+    if (layout == COLBWT_LAYOUT_AUTO) layout = default_layout();
+    if (layout != COLBWT_LAYOUT_ONE_STEP && layout != COLBWT_LAYOUT_TWO_STEP) return fail(COLBWT_ERR_ARG, "bad layout");
     *out = nullptr;
     if (!widths_ok(widths))
         return fail(COLBWT_ERR_ARG, "only the shipped widths BWT_BYTES=5 RUN_BYTES=4 LEN_BYTES=2 ID_BITS=8 are supported");
     colbwt_index *idx = new (std::nothrow) colbwt_index();
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
-    int rc = idx->ix.load((const uint8_t *)bytes, len, device, err);
+    int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
     if (rc != COLBWT_OK) {
         delete idx;
         return fail(rc, err);
@@ -195,6 +214,11 @@ int colbwt_index_open_memory(const void *bytes, uint64_t len, const colbwt_width
 }
 
 int colbwt_index_open(const char *prefix_or_file, const colbwt_widths *widths, int device, colbwt_index **out) {
+    return colbwt_index_open_layout(prefix_or_file, widths, device, COLBWT_LAYOUT_AUTO, out);
+}
+
+int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
+                             colbwt_index **out) {
     if (!prefix_or_file || !out) return fail(COLBWT_ERR_ARG, "null argument");
     *out = nullptr;
     // pml_query.cpp:110-111: filename = prefix + ".col_pml" (col_bwt.hpp:434-437)
@@ -205,9 +229,9 @@ int colbwt_index_open(const char *prefix_or_file, const colbwt_widths *widths, i
         path = prefix_or_file;
         if (!direct.open(path))
             return fail(COLBWT_ERR_IO, std::string("cannot open ") + prefix_or_file + ".col_pml (or " + prefix_or_file + ")");
-        return colbwt_index_open_memory(direct.data, direct.len, widths, device, out);
+        return colbwt_index_open_memory_layout(direct.data, direct.len, widths, device, layout, out);
     }
-    return colbwt_index_open_memory(mf.data, mf.len, widths, device, out);
+    return colbwt_index_open_memory_layout(mf.data, mf.len, widths, device, layout, out);
 }
 
 void colbwt_index_close(colbwt_index *idx) { delete idx; }
@@ -220,6 +244,9 @@ int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
     out->sigma = idx->ix.sigma();
     out->device = (uint32_t)idx->ix.device();
     out->device_bytes = idx->ix.device_bytes();
+    out->layout = (uint32_t)idx->ix.layout();
+    out->reserved_ = 0;
+    out->table_rows = idx->ix.table_rows();
     return COLBWT_OK;
 }
 
@@ -260,7 +287,10 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
         API_HIP(hipEventCreate(&e1));
         API_HIP(hipEventRecord(e0, stream));
     }
-    launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+    if (idx->ix.layout() == 2)
+        launch_s2_query(idx->ix.table2(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+    else
+        launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     API_HIP(hipGetLastError());
     if (stats) {
         API_HIP(hipEventRecord(e1, stream));

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "device_layout.h"
+#include "s2_layout.h"
 
 namespace colbwt {
 
@@ -24,9 +25,13 @@ public:
 
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
-    int load(const uint8_t *bytes, uint64_t len, int device, std::string &err);
+    // layout: 1 = one-step (device_layout.h), 2 = two-step (s2_layout.h, built on top of 1).
+    int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err);
 
     const DevTable &table() const { return tbl_; }
+    const S2Table &table2() const { return tbl2_; }
+    int layout() const { return layout_; }
+    uint64_t table_rows() const { return layout_ == 2 ? tbl2_.r2 : tbl_.r; }
     int device() const { return device_; }
     uint64_t bwt_r() const { return bwt_r_; }
     uint64_t n() const { return tbl_.n; }
@@ -37,6 +42,9 @@ public:
 private:
     void release();
     DevTable tbl_{};
+    S2Table tbl2_{};
+    int layout_ = 1;
+    void *d2_lines_ = nullptr, *d2_thr_ = nullptr, *d2_next_ = nullptr, *d2_prev_ = nullptr;
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t device_bytes_ = 0;

@@ -48,7 +48,7 @@ Index::~Index() { release(); }
 
 void Index::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    for (void **p : {&d_rows_, &d_thr_, &d_next_, &d_prev_, &d_cmap_}) {
+    for (void **p : {&d_rows_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -61,7 +61,7 @@ static inline uint64_t rd_u64(const uint8_t *p) {
     return v;
 }
 
-int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err) {
+int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err) {
     if (!bytes || len < kHeaderBytes) {
         err = "index image shorter than its 32-byte header";
         return COLBWT_ERR_FORMAT;
@@ -213,6 +213,18 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, std::string &err
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(0));
         tbl_.use_hints = 1;
+
+        // ---- optional two-step layout on top (s2_layout.h)
+        layout_ = 1;
+        if (layout == 2) {
+            uint64_t bytes2 = 0;
+            if (!build_s2(tbl_, hc, tbl2_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_, bytes2, err)) {
+                release();
+                return COLBWT_ERR_NOMEM;
+            }
+            device_bytes_ += bytes2;
+            layout_ = 2;
+        }
     }
     return COLBWT_OK;
 }

@@ -15,6 +15,16 @@ void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t 
                       uint64_t n_reads, void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order,
                       hipStream_t stream);
 
+}  // namespace colbwt
+#include <string>
+
+#include "s2_layout.h"
+namespace colbwt {
+
+// The same query over the two-step layout (s2_query.hip).
+void launch_s2_query(const S2Table &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                     void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
+
 // ---- load-time kernels (index_kernels.hip) --------------------------------
 struct RelayoutReport {
     uint32_t flags;      // bit0 idx not strictly increasing, bit1 interval >= r, bit2 idx >= n, bit3 idx[0] != 0
@@ -35,6 +45,10 @@ struct HintChars {
     uint8_t c[8];
 };
 void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream);
+
+// Two-step layout from the one-step tables (s2_build.hip); false + err when it cannot be built.
+bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_thr, void **d_next,
+              void **d_prev, uint64_t &bytes, std::string &err);
 
 // Backward-walk read sampler (synthetic benchmark input).
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,

@@ -29,14 +29,17 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def check(image, reads, label, wide=False):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
-    tbl = pkg.ColPml.from_bytes(image)
     ref = oracle.OracleIndex(image)
-    pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
     epml, ecid = ref.query_batch(bases, off, wide=wide)
-    assert np.array_equal(pml, epml), f"{label}: PML differs at {np.flatnonzero(pml != epml)[:5]}"
-    assert np.array_equal(cid, ecid), f"{label}: CID differs at {np.flatnonzero(cid != ecid)[:5]}"
-    tbl.close()
-    print(f"ok {label}: {len(reads)} reads, {int(off[-1])} bases")
+    for layout in (1, 2):            # one-step rows / two-step refined rows: identical results
+        tbl = pkg.ColPml.from_bytes(image, layout=layout)
+        assert tbl.info().layout == layout
+        pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
+        assert np.array_equal(pml, epml), f"{label}/L{layout}: PML differs at {np.flatnonzero(pml != epml)[:5]}"
+        assert np.array_equal(cid, ecid), f"{label}/L{layout}: CID differs at {np.flatnonzero(cid != ecid)[:5]}"
+        rows2 = tbl.info().table_rows
+        tbl.close()
+    print(f"ok {label}: {len(reads)} reads, {int(off[-1])} bases (two-step table: {rows2} rows)")
 
 
 def rand_reads(rng, n, lo, hi, alphabet=b"ACGT"):

@@ -28,13 +28,15 @@ def _loaded_hip_lib(pkg):
 def _check(pkg, oracle, image, reads, wide=False):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
-    tbl = pkg.ColPml.from_bytes(image)
     ref = oracle.OracleIndex(image)
-    pml, cid, st = tbl.query_batch(bases, off, wide=wide)
     epml, ecid = ref.query_batch(bases, off, wide=wide, threads=8)
-    assert np.array_equal(pml, epml), f"PML differs at {np.flatnonzero(pml != epml)[:8]}"
-    assert np.array_equal(cid, ecid), f"col-id differs at {np.flatnonzero(cid != ecid)[:8]}"
-    tbl.close()
+    for layout in (1, 2):     # one-step rows and two-step refined rows must both be bit-exact
+        tbl = pkg.ColPml.from_bytes(image, layout=layout)
+        assert tbl.info().layout == layout
+        pml, cid, st = tbl.query_batch(bases, off, wide=wide)
+        assert np.array_equal(pml, epml), f"layout {layout}: PML differs at {np.flatnonzero(pml != epml)[:8]}"
+        assert np.array_equal(cid, ecid), f"layout {layout}: col-id differs at {np.flatnonzero(cid != ecid)[:8]}"
+        tbl.close()
     return st
 
 
@@ -216,7 +218,8 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
     assert 0.02 < resets < 0.6          # the recipe's mix of extends and resets
 
 
-def test_full_scale_properties(pkg, oracle):
+@pytest.mark.parametrize("layout", [1, 2])
+def test_full_scale_properties(pkg, oracle, layout):
     """BASELINE config C2 scale (2e8 rows): size-independent properties --
     idempotence (two runs, identical bytes), batch-position independence (a
     permuted sub-batch gives the same per-read values) and oracle agreement on
@@ -226,7 +229,7 @@ def test_full_scale_properties(pkg, oracle):
     n_reads, m = int(os.environ.get("COLBWT_TEST_READS", "2000000")), 150
     dev = torch.device("cuda", 0)
     image = pkg.synth_index(rows, mean_len=8, split_permille=0, seed=42)
-    tbl = pkg.ColPml.from_bytes(image)
+    tbl = pkg.ColPml.from_bytes(image, layout=layout)
     d_bases = torch.zeros(n_reads * m + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     s = torch.cuda.current_stream().cuda_stream

@@ -30,7 +30,8 @@ def bind(path):
     L = C.CDLL(path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
     L.colbwt_last_error.restype = C.c_char_p
-    L.colbwt_index_open_memory.argtypes = [vp, u64, vp, i32, C.POINTER(vp)]
+    L.colbwt_index_open_memory_layout.argtypes = [vp, u64, vp, i32, i32, C.POINTER(vp)]
+    L.colbwt_index_info.argtypes = [vp, vp]
     L.colbwt_query_device.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, C.POINTER(Stats)]
     L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     return L
@@ -54,12 +55,13 @@ def main():
     d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     variants = []
-    for path in a.libs:
+    for spec in a.libs:                      # "lib.so" or "lib.so@2" (HBM table layout)
+        path, _, lay = spec.partition("@")
         L = bind(os.path.abspath(path))
         h = C.c_void_p()
-        rc = L.colbwt_index_open_memory(image.ctypes.data, image.size, None, 0, C.byref(h))
+        rc = L.colbwt_index_open_memory_layout(image.ctypes.data, image.size, None, 0, int(lay or 0), C.byref(h))
         assert rc == 0, L.colbwt_last_error()
-        variants.append((os.path.basename(path), L, h, []))
+        variants.append((os.path.basename(spec), L, h, []))
     name0, L0, h0, _ = variants[0]
     assert L0.colbwt_synth_reads_device(h0, n_reads, m, a.sub_permille, 43, d_bases.data_ptr(), d_off.data_ptr(), None) == 0
     torch.cuda.synchronize()
