@@ -10,8 +10,14 @@
 //       .x  interval                      (32)   LF_row::interval
 //       .y  offset | len16 << 16          (16+16) LF_row::offset ; run length,
 //                                          0xFFFF = "long": idx[j+1]-idx[j]
-//       .z  idx low 32 bits                      LF_row::idx
-//       .w  idx high 8 | char << 8 | col_id << 16 | hints << 24
+//       .z  len8 of row j+1 | len8 of row j+2 << 8 (0xFF = long / none): the
+//           fast-forward loop (LF_table.hpp:256-259) hops up to three rows per
+//           memory round trip instead of one;
+//           | dist << 16: 4 bits per hint slot, the distance in rows to the run a
+//           mismatch on that character re-orients to (the predecessor when the
+//           hint says pred-side, else the successor; 15 = scan for it): a
+//           mismatch then costs one row load instead of a scan plus a row load
+//       .w  (spare 8) | char << 8 | col_id << 16 | hints << 24
 //     hints: 2 bits for each of the 4 most frequent OTHER characters c (dense
 //     character indices are ordered by frequency), precomputed at
 //     load: how `pos < threshold(succ_c(row))` (col_bwt.hpp:560) comes out for
@@ -21,7 +27,10 @@
 //     scans on almost every mismatch.
 //     row r is a sentinel with idx = n, so len(j) = idx[j+1]-idx[j] holds for
 //     the last row too (LF_table.hpp:206 special-cases it).
-//   thr[r]     u64 thresholds (col_thr::threshold), touched only on a mismatch.
+//   idx[r+1]   u64 BWT position of each row's first character (LF_row::idx;
+//              idx[r] = n).  COLD: only a compare-hint mismatch (pos), a long
+//              run's length and the load-time kernels read it.
+//   thr[r]     u64 thresholds (col_thr::threshold), compare-hint mismatches only.
 //   next_tbl / prev_tbl  [nblk][sigma] u32: first run >= b*B / last run < b*B
 //     holding each present character; bound the succ_char / pred_char scans
 //     (LF_table.hpp:271-298 are unbounded linear scans) to one block of B rows.
@@ -41,11 +50,14 @@ constexpr uint32_t kAbsent = 0xFFu;         // cmap: byte not in the BWT
 constexpr uint32_t kAlgBytesPerBase = 27;
 constexpr uint32_t kHintPred = 0, kHintSucc = 1, kHintCompare = 2;
 constexpr uint32_t kHintAllCompare = 0xAAu; // every slot = kHintCompare
+constexpr uint32_t kLen8Long = 0xFFu;       // .z next-row length escape
+constexpr uint32_t kDistFar = 15u;          // .z distance nibble: target not within 14 rows / unknown
 constexpr uint32_t kHintSlots = 4;          // 2 bits each in the row's spare byte
 constexpr uint32_t kHintMaxSigma = 5;       // characters that can own a slot: the 5 most frequent
 
 struct DevTable {
-    const uint4 *rows;        // r + 1
+    const uint4 *rows;        // r + 1 (padded to whole lines)
+    const uint64_t *idx;      // r + 1
     const uint64_t *thr;      // r
     const uint32_t *next_tbl; // nblk * sigma
     const uint32_t *prev_tbl; // nblk * sigma

@@ -48,7 +48,7 @@ private:
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t device_bytes_ = 0;
-    void *d_rows_ = nullptr, *d_thr_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr, *d_cmap_ = nullptr;
+    void *d_rows_ = nullptr, *d_idx_ = nullptr, *d_thr_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr, *d_cmap_ = nullptr;
 };
 
 // Selects `device` after checking that a usable gfx950-class HIP device exists.

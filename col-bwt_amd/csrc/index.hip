@@ -48,7 +48,7 @@ Index::~Index() { release(); }
 
 void Index::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    for (void **p : {&d_rows_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_}) {
+    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -97,9 +97,10 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     const uint64_t rows_alloc = ((r + 1 + 7) & ~7ull) * sizeof(uint4);
     HIP_TRY(hipMalloc(&d_rows_, rows_alloc));
     HIP_TRY(hipMemset(d_rows_, 0, rows_alloc));
+    HIP_TRY(hipMalloc(&d_idx_, (r + 1) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&d_thr_, r * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&d_cmap_, 256));
-    device_bytes_ = rows_alloc + r * sizeof(uint64_t) + 256;
+    device_bytes_ = rows_alloc + (2 * r + 1) * sizeof(uint64_t) + 256;
 
     // ---- upload packed rows chunk by chunk and re-lay them out on the device
     RelayoutReport *d_report = nullptr;
@@ -111,10 +112,10 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     const uint64_t chunk_rows = 16ull << 20;  // 288 MiB of packed rows per staging pass
     const uint64_t stage_rows = std::min<uint64_t>(chunk_rows, r);
     uint8_t *d_raw = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_raw, (stage_rows + 1) * kRowBytesDisk + 64));
+    HIP_TRY(hipMalloc((void **)&d_raw, (stage_rows + 3) * kRowBytesDisk + 64));
     for (uint64_t row0 = 0; row0 < r; row0 += chunk_rows) {
         const uint64_t count = std::min<uint64_t>(chunk_rows, r - row0);
-        const uint64_t with_next = std::min<uint64_t>(count + 1, r - row0);  // next row's idx for run lengths
+        const uint64_t with_next = std::min<uint64_t>(count + 3, r - row0);  // following rows' idx for run lengths
         hipError_t e = hipMemcpy(d_raw, rows_disk + row0 * kRowBytesDisk, with_next * kRowBytesDisk,
                                  hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -123,7 +124,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
             err = std::string("hipMemcpy(rows): ") + hipGetErrorString(e);
             return COLBWT_ERR_HIP;
         }
-        launch_relayout(d_raw, row0, count, r, n, (uint4 *)d_rows_, (uint64_t *)d_thr_, d_report, 0);
+        launch_relayout(d_raw, row0, count, r, n, (uint4 *)d_rows_, (uint64_t *)d_idx_, (uint64_t *)d_thr_, d_report, 0);
         HIP_TRY(hipStreamSynchronize(0));
     }
     (void)hipFree(d_raw);
@@ -194,6 +195,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     }
 
     tbl_.rows = (const uint4 *)d_rows_;
+    tbl_.idx = (const uint64_t *)d_idx_;
     tbl_.thr = (const uint64_t *)d_thr_;
     tbl_.next_tbl = (const uint32_t *)d_next_;
     tbl_.prev_tbl = (const uint32_t *)d_prev_;

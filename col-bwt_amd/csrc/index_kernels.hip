@@ -13,7 +13,8 @@ namespace colbwt {
 namespace {
 
 constexpr uint32_t kRelayoutBlock = 256;
-constexpr uint32_t kStageBytes = kRelayoutBlock * kRowBytesDisk + 24;  // block's rows + next row's idx, dword padded
+constexpr uint32_t kStageExtra = 3;                                    // following rows whose idx is needed
+constexpr uint32_t kStageBytes = (kRelayoutBlock + kStageExtra) * kRowBytesDisk + 8;
 
 __device__ __forceinline__ uint64_t lds_le(const uint8_t *p, uint32_t nbytes) {
     uint64_t v = 0;
@@ -27,8 +28,8 @@ __device__ __forceinline__ uint64_t lds_le(const uint8_t *p, uint32_t nbytes) {
 // (memory image of col_thr: LF_table.hpp:33-40, col_bwt.hpp:43,84).
 __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t *__restrict__ raw, uint64_t row0,
                                                                   uint64_t count, uint64_t r, uint64_t n,
-                                                                  uint4 *__restrict__ rows, uint64_t *__restrict__ thr,
-                                                                  RelayoutReport *report) {
+                                                                  uint4 *__restrict__ rows, uint64_t *__restrict__ idx_out,
+                                                                  uint64_t *__restrict__ thr, RelayoutReport *report) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
     __shared__ uint32_t s_present[8];
     __shared__ uint32_t s_count[256];
@@ -39,9 +40,10 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
     if (threadIdx.x == 0) { s_flags = 0; s_bad = kNone; }
 
     const uint64_t rows_here = (count - blk_row) < kRelayoutBlock ? (count - blk_row) : kRelayoutBlock;
-    // bytes of this block's rows, plus 6 bytes (char + idx) of the following row when it exists
-    const bool has_next = (row0 + blk_row + rows_here) < r;
-    const uint32_t need = (uint32_t)rows_here * kRowBytesDisk + (has_next ? 6u : 0u);
+    // bytes of this block's rows, plus the following (up to 3) rows whose idx gives run lengths
+    const uint64_t after = r - (row0 + blk_row + rows_here);
+    const uint32_t extra = after < kStageExtra ? (uint32_t)after : kStageExtra;
+    const uint32_t need = ((uint32_t)rows_here + extra) * kRowBytesDisk;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(raw + blk_row * kRowBytesDisk);  // 4608*k: dword aligned
     uint32_t *dst = reinterpret_cast<uint32_t *>(stage);
     for (uint32_t d = threadIdx.x; d * 4 < need; d += kRelayoutBlock) dst[d] = src[d];
@@ -56,7 +58,10 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         const uint32_t offset = (uint32_t)lds_le(p + 10, 2);
         const uint32_t cid = p[12];
         const uint64_t threshold = lds_le(p + 13, 5);
+        // idx of rows i+1 .. i+3 (n past the end): lengths of this row and of the next two
         const uint64_t next_idx = (i + 1 < r) ? lds_le(p + kRowBytesDisk + 1, 5) : n;
+        const uint64_t next2_idx = (i + 2 < r) ? lds_le(p + 2 * kRowBytesDisk + 1, 5) : n;
+        const uint64_t next3_idx = (i + 3 < r) ? lds_le(p + 3 * kRowBytesDisk + 1, 5) : n;
 
         uint32_t flags = 0;
         if (next_idx <= idx) flags |= (i + 1 < r) ? 1u : 4u;  // not strictly increasing / last idx >= n
@@ -68,10 +73,17 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         }
         const uint64_t len = next_idx - idx;
         const uint32_t len16 = len < kLenLong ? (uint32_t)len : kLenLong;
-        rows[i] = make_uint4(interval, offset | (len16 << 16), (uint32_t)idx,
-                             (uint32_t)(idx >> 32) | (ch << 8) | (cid << 16) | (kHintAllCompare << 24));
+        const uint64_t len1 = next2_idx - next_idx, len2 = next3_idx - next2_idx;
+        const uint32_t l1 = (i + 1 < r && next2_idx > next_idx && len1 < kLen8Long) ? (uint32_t)len1 : kLen8Long;
+        const uint32_t l2 = (i + 2 < r && next3_idx > next2_idx && len2 < kLen8Long) ? (uint32_t)len2 : kLen8Long;
+        rows[i] = make_uint4(interval, offset | (len16 << 16), l1 | (l2 << 8) | 0xFFFF0000u,
+                             (ch << 8) | (cid << 16) | (kHintAllCompare << 24));
+        idx_out[i] = idx;
         thr[i] = threshold;
-        if (i + 1 == r) rows[r] = make_uint4(0, 0, (uint32_t)n, (uint32_t)(n >> 32));  // sentinel: idx = n
+        if (i + 1 == r) {  // sentinel row: idx = n
+            rows[r] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+            idx_out[r] = n;
+        }
         atomicOr(&s_present[ch >> 5], 1u << (ch & 31));
         atomicAdd(&s_count[ch], 1u);
     }
@@ -131,9 +143,9 @@ __global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, H
     const uint32_t i = (uint32_t)i64;
     const uint4 w = T.rows[i];
     const uint32_t aidx = T.cmap[row_char(w)];
-    const uint64_t lo = row_idx(w);
+    const uint64_t lo = row_idx(T, i);
     const uint64_t hi = lo + row_len(T, i, w) - 1;
-    uint32_t hints = kHintAllCompare;
+    uint32_t hints = kHintAllCompare, dists = 0xFFFFu;
     // dense indices are ordered by character frequency: the 4 hint slots of a row go to the
     // 4 most frequent OTHER characters (cidx <= 4); rarer ones compare at query time
     const uint32_t top = T.sigma < kHintMaxSigma ? T.sigma : kHintMaxSigma;
@@ -143,8 +155,18 @@ __global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, H
         const uint32_t s = succ_char(T, i, chars.c[cidx], cidx, t);
         const uint64_t thr = (s != kNone) ? T.thr[s] : T.n;   // :535 thr = n when there is no successor
         const uint32_t code = hi < thr ? kHintPred : (lo >= thr ? kHintSucc : kHintCompare);
-        hints = (hints & ~(3u << (2 * hint_slot(cidx, aidx)))) | (code << (2 * hint_slot(cidx, aidx)));
+        const uint32_t slot = hint_slot(cidx, aidx);
+        hints = (hints & ~(3u << (2 * slot))) | (code << (2 * slot));
+        // where a mismatch on this character re-orients to, when it is decided and close
+        uint32_t dist = kDistFar;
+        if (code == kHintSucc && s - i < kDistFar) dist = s - i;          // s exists: thr <= lo < n
+        if (code == kHintPred) {
+            const uint32_t q = pred_char(T, i, chars.c[cidx], cidx, t);
+            if (q != kNone && i - q < kDistFar) dist = i - q;             // no predecessor: scan at query time
+        }
+        dists = (dists & ~(0xFu << (4 * slot))) | (dist << (4 * slot));
     }
+    rows_rw[i].z = (w.z & 0x0000FFFFu) | (dists << 16);
     rows_rw[i].w = (w.w & 0x00FFFFFFu) | (hints << 24);
 }
 
@@ -155,7 +177,6 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ uint64_t d_row_idx(const uint4 &w) { return row_idx(w); }
 
 // Synthetic reads by backward walk: read[m-1-k] = char at
 // LF^k(p0).  Generator only -- results are inputs, never checked outputs.
@@ -173,11 +194,11 @@ __global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n
     uint64_t lo = 0, hi = T.r;  // idx[lo] <= p0 < idx[hi] (sentinel idx[r] = n)
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (d_row_idx(T.rows[mid]) <= p0) lo = mid; else hi = mid;
+        if (T.idx[mid] <= p0) lo = mid; else hi = mid;
     }
     uint32_t i = (uint32_t)lo;
     uint4 w = T.rows[i];
-    uint64_t o = p0 - d_row_idx(w);
+    uint64_t o = p0 - T.idx[i];
     uint8_t *out = bases + rd * m;
     const char acgt[4] = {'A', 'C', 'G', 'T'};
     for (uint32_t k = 0; k < m; ++k) {
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n
         uint64_t t = (uint64_t)(w.y & 0xFFFFu) + o;
         w = T.rows[j];
         for (;;) {
-            const uint64_t len = d_row_idx(T.rows[(uint64_t)j + 1]) - d_row_idx(w);
+            const uint64_t len = T.idx[(uint64_t)j + 1] - T.idx[j];
             if (t < len || j >= T.r - 1) break;
             t -= len;
             ++j;
@@ -209,11 +230,11 @@ __global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n
 }  // namespace
 
 void launch_relayout(const uint8_t *d_raw, uint64_t row0, uint64_t count, uint64_t r, uint64_t n, uint4 *d_rows,
-                     uint64_t *d_thr, RelayoutReport *d_report, hipStream_t stream) {
+                     uint64_t *d_idx, uint64_t *d_thr, RelayoutReport *d_report, hipStream_t stream) {
     if (count == 0) return;
     const uint32_t blocks = (uint32_t)((count + kRelayoutBlock - 1) / kRelayoutBlock);
     hipLaunchKernelGGL(relayout_kernel, dim3(blocks), dim3(kRelayoutBlock), 0, stream, d_raw, row0, count, r, n,
-                       d_rows, d_thr, d_report);
+                       d_rows, d_idx, d_thr, d_report);
 }
 
 void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uint32_t sigma, const uint8_t *d_cmap,

@@ -15,9 +15,10 @@ namespace colbwt {
 __device__ __forceinline__ uint32_t row_interval(const uint4 &w) { return w.x; }
 __device__ __forceinline__ uint32_t row_offset(const uint4 &w) { return w.y & 0xFFFFu; }
 __device__ __forceinline__ uint32_t row_len16(const uint4 &w) { return w.y >> 16; }
-__device__ __forceinline__ uint64_t row_idx(const uint4 &w) {
-    return (uint64_t)w.z | ((uint64_t)(w.w & 0xFFu) << 32);
-}
+__device__ __forceinline__ uint32_t row_len8_next1(const uint4 &w) { return w.z & 0xFFu; }
+__device__ __forceinline__ uint32_t row_len8_next2(const uint4 &w) { return (w.z >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t row_dist(const uint4 &w, uint32_t slot) { return (w.z >> (16 + 4 * slot)) & 0xFu; }
+__device__ __forceinline__ uint64_t row_idx(const DevTable &T, uint32_t j) { return T.idx[j]; }
 __device__ __forceinline__ uint32_t row_char(const uint4 &w) { return (w.w >> 8) & 0xFFu; }
 __device__ __forceinline__ uint32_t row_cid(const uint4 &w) { return (w.w >> 16) & 0xFFu; }
 __device__ __forceinline__ uint32_t row_hints(const uint4 &w) { return w.w >> 24; }
@@ -26,8 +27,7 @@ __device__ __forceinline__ uint32_t row_hints(const uint4 &w) { return w.w >> 24
 __device__ __forceinline__ uint64_t row_len(const DevTable &T, uint32_t j, const uint4 &w) {
     const uint32_t l16 = row_len16(w);
     if (__builtin_expect(l16 != kLenLong, 1)) return l16;
-    const uint4 nx = T.rows[(uint64_t)j + 1];
-    return row_idx(nx) - row_idx(w);
+    return T.idx[(uint64_t)j + 1] - T.idx[j];
 }
 
 // Rows are 16 bytes, 8 per 128-byte HBM line.  The scans below walk line by

@@ -33,10 +33,11 @@ struct RelayoutReport {
     uint32_t count[256]; // rows per character (orders the dense character indices by frequency)
 };
 
-// Packed 18-byte rows [row0, row0+count) (plus the following row's idx when it
-// exists) -> 16-byte rows + thresholds; validates as it goes.
+// Packed 18-byte rows [row0, row0+count) (plus up to 3 following rows, whose idx
+// give run lengths) -> 16-byte rows + idx + thresholds; validates as it goes.
 void launch_relayout(const uint8_t *d_raw, uint64_t row0, uint64_t count, uint64_t r, uint64_t n,
-                     uint4 *d_rows, uint64_t *d_thr, RelayoutReport *d_report, hipStream_t stream);
+                     uint4 *d_rows, uint64_t *d_idx, uint64_t *d_thr, RelayoutReport *d_report,
+                     hipStream_t stream);
 void launch_block_first_last(const uint4 *d_rows, uint32_t r, uint32_t nblk, uint32_t sigma,
                              const uint8_t *d_cmap, uint32_t *d_first, uint32_t *d_last, hipStream_t stream);
 

@@ -43,7 +43,23 @@ __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t 
     if (cidx == kAbsent) return;  // c occurs nowhere: (interval, offset) unchanged (:533-534)
     uint32_t hint = kHintCompare;
     const uint32_t slot = hint_slot(cidx, s_cmap[row_char(w)]);
-    if (slot < kHintSlots) hint = (row_hints(w) >> (2 * slot)) & 3u;   // rarer characters: compare
+    if (slot < kHintSlots) {
+        hint = (row_hints(w) >> (2 * slot)) & 3u;   // rarer characters: compare
+        const uint32_t dist = row_dist(w, slot);
+        if (dist != kDistFar && hint != kHintCompare) {
+            // decided and close: the target row's distance is in the row; one load, no scan
+            if (hint == kHintPred) {                         // :565-569
+                i -= dist;
+                w = T.rows[i];
+                o = row_len(T, i, w) - 1;                    // LF_table.hpp:282
+            } else {                                         // :552-557
+                i += dist;
+                w = T.rows[i];
+                o = 0;
+            }
+            return;
+        }
+    }
     uint4 t;
     if (hint == kHintPred) {
         // pos < thr for every offset of this row (or no successor, thr = n :535): pred wins if it exists
@@ -64,7 +80,7 @@ __device__ __forceinline__ void threshold_step(const DevTable &T, const uint8_t 
         if (s != kNone) { i = s; o = 0; w = t; }
         return;
     }
-    const uint64_t pos = row_idx(w) + o;  // LF_table::to_idx (LF_table.hpp:214-217)
+    const uint64_t pos = row_idx(T, i) + o;  // LF_table::to_idx (LF_table.hpp:214-217)
     uint64_t thr = T.n;                   // :535
     uint32_t ni = i;
     uint64_t no = o;
@@ -217,16 +233,28 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
         if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
 
-        // LF_table::LF (LF_table.hpp:251-262)
+        // LF_table::LF (LF_table.hpp:251-262).  A row also carries the lengths of the two rows
+        // after it, so the fast-forward (:256-259) hops up to three rows per memory round trip.
         uint32_t j = row_interval(w);                // :253
         uint64_t t = (uint64_t)row_offset(w) + o;    // :254
         w = T.rows[j];
-        uint64_t len = row_len(T, j, w);
-        while (t >= len && j < T.r - 1) {            // :256 (bounded: a validated table never passes r-1)
+        for (;;) {
+            const uint64_t len = row_len(T, j, w);
+            if (t < len || j >= T.r - 1) break;      // :256 (bounded: a validated table never passes r-1)
             t -= len;                                // :258
-            ++j;
+            uint32_t hop = 1;
+            const uint32_t l1 = row_len8_next1(w);
+            if (l1 != kLen8Long && t >= l1 && j + 1 < T.r - 1) {
+                t -= l1;
+                hop = 2;
+                const uint32_t l2 = row_len8_next2(w);
+                if (l2 != kLen8Long && t >= l2 && j + 2 < T.r - 1) {
+                    t -= l2;
+                    hop = 3;
+                }
+            }
+            j += hop;
             w = T.rows[j];
-            len = row_len(T, j, w);
         }
         i = j;
         o = t;

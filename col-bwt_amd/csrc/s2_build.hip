@@ -30,7 +30,7 @@ template <typename F>
 __device__ __forceinline__ void for_each_piece(const DevTable &T, uint32_t i, F f) {
     const uint4 w = T.rows[i];
     uint64_t rem = row_len(T, i, w);
-    uint64_t b = row_idx(w);
+    uint64_t b = row_idx(T, i);
     uint32_t j = row_interval(w);
     uint64_t t = row_offset(w);
     uint4 wj = T.rows[j];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void s2_link_kernel(DevTable T, const uint32_t
     const uint64_t t1 = (uint64_t)p[1] | ((uint64_t)p[2] << 32);
     const uint4 w1 = T.rows[j1];
     // one step: LF(first position) = idx[j1] + t1
-    const uint64_t pos1 = row_idx(w1) + t1;
+    const uint64_t pos1 = row_idx(T, j1) + t1;
     const uint32_t I1 = s2_find(lines, first2, j1, pos1);
     const uint32_t O1 = (uint32_t)(pos1 - s2_idx_at(lines, I1));
     // two steps: LF from (j1, t1) in original coordinates (LF_table.hpp:251-262)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void s2_link_kernel(DevTable T, const uint32_t
         wj = T.rows[j];
         lenj = row_len(T, j, wj);
     }
-    const uint64_t pos2 = row_idx(wj) + t;
+    const uint64_t pos2 = row_idx(T, j) + t;
     const uint32_t I2 = s2_find(lines, first2, j, pos2);
     const uint32_t O2 = (uint32_t)(pos2 - s2_idx_at(lines, I2));
     p[0] = I1;
