@@ -23,7 +23,7 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_ONE_STEP
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_TWO_STEP
 
 struct colbwt_index {
     Index ix;
@@ -196,7 +196,8 @@ int colbwt_index_open_memory(const void *bytes, uint64_t len, const colbwt_width
 int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbwt_widths *widths, int device,
                                     int layout, colbwt_index **out) {
     if (!out) return fail(COLBWT_ERR_ARG, "null out");
-    if (layout == COLBWT_LAYOUT_AUTO) layout = default_layout();
+    const bool automatic = layout == COLBWT_LAYOUT_AUTO;
+    if (automatic) layout = default_layout();
     if (layout != COLBWT_LAYOUT_ONE_STEP && layout != COLBWT_LAYOUT_TWO_STEP) return fail(COLBWT_ERR_ARG, "bad layout");
     *out = nullptr;
     if (!widths_ok(widths))
@@ -205,6 +206,10 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
     int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
+    if (rc == COLBWT_ERR_NOMEM && automatic && layout == COLBWT_LAYOUT_TWO_STEP) {
+        // the two-step table does not fit (HBM, or more than 2^32-2 refined rows): one-step rows
+        rc = idx->ix.load((const uint8_t *)bytes, len, device, COLBWT_LAYOUT_ONE_STEP, err);
+    }
     if (rc != COLBWT_OK) {
         delete idx;
         return fail(rc, err);

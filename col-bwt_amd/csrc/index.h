@@ -44,7 +44,7 @@ private:
     DevTable tbl_{};
     S2Table tbl2_{};
     int layout_ = 1;
-    void *d2_lines_ = nullptr, *d2_thr_ = nullptr, *d2_next_ = nullptr, *d2_prev_ = nullptr;
+    void *d2_lines_ = nullptr, *d2_idx_ = nullptr, *d2_thr_ = nullptr, *d2_next_ = nullptr, *d2_prev_ = nullptr;
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t device_bytes_ = 0;

@@ -48,7 +48,7 @@ Index::~Index() { release(); }
 
 void Index::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_}) {
+    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_idx_, &d2_thr_, &d2_next_, &d2_prev_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -220,7 +220,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         layout_ = 1;
         if (layout == 2) {
             uint64_t bytes2 = 0;
-            if (!build_s2(tbl_, hc, tbl2_, &d2_lines_, &d2_thr_, &d2_next_, &d2_prev_, bytes2, err)) {
+            if (!build_s2(tbl_, hc, tbl2_, &d2_lines_, &d2_idx_, &d2_thr_, &d2_next_, &d2_prev_, bytes2, err)) {
                 release();
                 return COLBWT_ERR_NOMEM;
             }

@@ -48,8 +48,8 @@ struct HintChars {
 void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream);
 
 // Two-step layout from the one-step tables (s2_build.hip); false + err when it cannot be built.
-bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_thr, void **d_next,
-              void **d_prev, uint64_t &bytes, std::string &err);
+bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_idx, void **d_thr,
+              void **d_next, void **d_prev, uint64_t &bytes, std::string &err);
 
 // Backward-walk read sampler (synthetic benchmark input).
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,

@@ -112,8 +112,8 @@ __device__ __forceinline__ uint32_t *s2_row_ptr(uint8_t *lines, uint32_t j) {
 }
 
 __global__ __launch_bounds__(256) void s2_emit_kernel(DevTable T, const uint32_t *__restrict__ first2,
-                                                      uint8_t *__restrict__ lines, uint64_t *__restrict__ thr2,
-                                                      uint32_t r2) {
+                                                      uint8_t *__restrict__ lines, uint64_t *__restrict__ idx2,
+                                                      uint64_t *__restrict__ thr2, uint32_t r2) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= T.r) return;
     const uint4 w = T.rows[i];
@@ -126,36 +126,32 @@ __global__ __launch_bounds__(256) void s2_emit_kernel(DevTable T, const uint32_t
         p[1] = (uint32_t)t;
         p[2] = (uint32_t)(t >> 32);
         p[3] = len | (ch << 16) | (cidv << 24);
-        p[4] = (uint32_t)b;
-        p[5] = (uint32_t)(b >> 32) | (kHintAllCompare << 24);
+        p[4] = 0xFFFFFFFFu;             // next-row lengths unknown, mismatch targets far (filled later)
+        p[5] = kHintAllCompare << 24;
+        idx2[out] = b;
         thr2[out] = thr;
         ++out;
     });
     if (i + 1 == T.r) {                 // sentinel refined row: idx = n
         uint32_t *p = s2_row_ptr(lines, r2);
-        p[0] = p[1] = p[2] = p[3] = 0;
-        p[4] = (uint32_t)T.n;
-        p[5] = (uint32_t)(T.n >> 32);
+        p[0] = p[1] = p[2] = p[3] = p[5] = 0;
+        p[4] = 0xFFFFFFFFu;
+        idx2[r2] = T.n;
     }
 }
 
-__device__ __forceinline__ uint64_t s2_idx_at(const uint8_t *lines, uint32_t j) {
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(lines + s2_row_off(j));
-    return (uint64_t)p[4] | ((uint64_t)(p[5] & 0xFFu) << 32);
-}
-
 // Refined row holding BWT position `pos`, which lies in original row j.
-__device__ __forceinline__ uint32_t s2_find(const uint8_t *lines, const uint32_t *first2, uint32_t j, uint64_t pos) {
+__device__ __forceinline__ uint32_t s2_find(const uint64_t *idx2, const uint32_t *first2, uint32_t j, uint64_t pos) {
     uint32_t lo = first2[j], hi = first2[j + 1];   // rows lo .. hi-1 tile original row j
     while (hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (s2_idx_at(lines, mid) <= pos) lo = mid; else hi = mid;
+        if (idx2[mid] <= pos) lo = mid; else hi = mid;
     }
     return lo;
 }
 
 __global__ __launch_bounds__(256) void s2_link_kernel(DevTable T, const uint32_t *__restrict__ first2,
-                                                      uint8_t *lines, uint32_t r2) {
+                                                      uint8_t *lines, const uint64_t *__restrict__ idx2, uint32_t r2) {
     const uint64_t i2 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i2 >= r2) return;
     uint32_t *p = s2_row_ptr(lines, (uint32_t)i2);
@@ -164,8 +160,8 @@ __global__ __launch_bounds__(256) void s2_link_kernel(DevTable T, const uint32_t
     const uint4 w1 = T.rows[j1];
     // one step: LF(first position) = idx[j1] + t1
     const uint64_t pos1 = row_idx(T, j1) + t1;
-    const uint32_t I1 = s2_find(lines, first2, j1, pos1);
-    const uint32_t O1 = (uint32_t)(pos1 - s2_idx_at(lines, I1));
+    const uint32_t I1 = s2_find(idx2, first2, j1, pos1);
+    const uint32_t O1 = (uint32_t)(pos1 - idx2[I1]);
     // two steps: LF from (j1, t1) in original coordinates (LF_table.hpp:251-262)
     uint32_t j = row_interval(w1);
     uint64_t t = (uint64_t)row_offset(w1) + t1;
@@ -178,11 +174,22 @@ __global__ __launch_bounds__(256) void s2_link_kernel(DevTable T, const uint32_t
         lenj = row_len(T, j, wj);
     }
     const uint64_t pos2 = row_idx(T, j) + t;
-    const uint32_t I2 = s2_find(lines, first2, j, pos2);
-    const uint32_t O2 = (uint32_t)(pos2 - s2_idx_at(lines, I2));
+    const uint32_t I2 = s2_find(idx2, first2, j, pos2);
+    const uint32_t O2 = (uint32_t)(pos2 - idx2[I2]);
     p[0] = I1;
     p[1] = I2;
     p[2] = (O1 & 0xFFFFu) | (O2 << 16);
+    // lengths of the next two refined rows (multi-hop fast-forward)
+    uint32_t l1 = kLen8Long, l2 = kLen8Long;
+    if (i2 + 1 < r2) {
+        const uint64_t a = idx2[i2 + 2] - idx2[i2 + 1];
+        if (a < kLen8Long) l1 = (uint32_t)a;
+    }
+    if (i2 + 2 < r2) {
+        const uint64_t a = idx2[i2 + 3] - idx2[i2 + 2];
+        if (a < kLen8Long) l2 = (uint32_t)a;
+    }
+    p[4] = l1 | (l2 << 8) | 0xFFFF0000u;
     p[5] = (p[5] & 0xFF0000FFu) | (row_char(w1) << 8) | (row_cid(w1) << 16);
 }
 
@@ -229,9 +236,9 @@ __global__ __launch_bounds__(256) void s2_hint_kernel(S2Table T, uint8_t *lines_
     const uint32_t i = (uint32_t)i64;
     const S2Row w = s2_load(T, i);
     const uint32_t aidx = T.cmap[s2_char(w)];
-    const uint64_t lo = s2_idx(w);
+    const uint64_t lo = T.idx[i];
     const uint64_t hi = lo + s2_len(w) - 1;
-    uint32_t hints = kHintAllCompare;
+    uint32_t hints = kHintAllCompare, dists = 0xFFFFu;
     const uint32_t top = T.sigma < kHintMaxSigma ? T.sigma : kHintMaxSigma;
     for (uint32_t cidx = 0; cidx < top; ++cidx) {
         if (cidx == aidx || hint_slot(cidx, aidx) >= kHintSlots) continue;
@@ -239,9 +246,18 @@ __global__ __launch_bounds__(256) void s2_hint_kernel(S2Table T, uint8_t *lines_
         const uint32_t s = s2_succ_char(T, i, chars.c[cidx], cidx, t);
         const uint64_t thr = (s != kNone) ? T.thr[s] : T.n;
         const uint32_t code = hi < thr ? kHintPred : (lo >= thr ? kHintSucc : kHintCompare);
-        hints = (hints & ~(3u << (2 * hint_slot(cidx, aidx)))) | (code << (2 * hint_slot(cidx, aidx)));
+        const uint32_t slot = hint_slot(cidx, aidx);
+        hints = (hints & ~(3u << (2 * slot))) | (code << (2 * slot));
+        uint32_t dist = kDistFar;
+        if (code == kHintSucc && s - i < kDistFar) dist = s - i;
+        if (code == kHintPred) {
+            const uint32_t q = s2_pred_char(T, i, chars.c[cidx], cidx, t);
+            if (q != kNone && i - q < kDistFar) dist = i - q;
+        }
+        dists = (dists & ~(0xFu << (4 * slot))) | (dist << (4 * slot));
     }
     uint32_t *p = s2_row_ptr(lines_rw, i);
+    p[4] = (w.d[4] & 0x0000FFFFu) | (dists << 16);
     p[5] = (w.d[5] & 0x00FFFFFFu) | (hints << 24);
 }
 
@@ -258,8 +274,8 @@ __global__ __launch_bounds__(256) void s2_hint_kernel(S2Table T, uint8_t *lines_
 
 // Builds the two-step layout from the one-step tables of `T`.  Returns false with
 // `err` set when it cannot (more than 2^32-2 refined rows, out of memory).
-bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_thr, void **d_next,
-              void **d_prev, uint64_t &bytes, std::string &err) {
+bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_idx, void **d_thr,
+              void **d_next, void **d_prev, uint64_t &bytes, std::string &err) {
     const uint64_t r = T.r;
     uint32_t *d_first2 = nullptr, *d_tot = nullptr;
     S2_TRY(hipMalloc((void **)&d_first2, (r + 1) * sizeof(uint32_t)));
@@ -296,16 +312,20 @@ bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_
     const uint64_t nlines = ((uint64_t)r2 + 1 + kS2RowsPerLine - 1) / kS2RowsPerLine + 1;
     S2_TRY(hipMalloc(d_lines, nlines * 128));
     S2_TRY(hipMemset(*d_lines, 0, nlines * 128));
+    S2_TRY(hipMalloc(d_idx, ((uint64_t)r2 + 4) * sizeof(uint64_t)));
+    S2_TRY(hipMemset(*d_idx, 0xFF, ((uint64_t)r2 + 4) * sizeof(uint64_t)));
     S2_TRY(hipMalloc(d_thr, (uint64_t)r2 * sizeof(uint64_t)));
     hipLaunchKernelGGL(s2_emit_kernel, dim3(rblocks), dim3(256), 0, 0, T, d_first2, (uint8_t *)*d_lines,
-                       (uint64_t *)*d_thr, r2);
+                       (uint64_t *)*d_idx, (uint64_t *)*d_thr, r2);
     S2_TRY(hipStreamSynchronize(0));
     const uint32_t r2blocks = (uint32_t)(((uint64_t)r2 + 255) / 256);
-    hipLaunchKernelGGL(s2_link_kernel, dim3(r2blocks), dim3(256), 0, 0, T, d_first2, (uint8_t *)*d_lines, r2);
+    hipLaunchKernelGGL(s2_link_kernel, dim3(r2blocks), dim3(256), 0, 0, T, d_first2, (uint8_t *)*d_lines,
+                       (const uint64_t *)*d_idx, r2);
     S2_TRY(hipStreamSynchronize(0));
     (void)hipFree(d_first2);
 
     out.lines = (const uint8_t *)*d_lines;
+    out.idx = (const uint64_t *)*d_idx;
     out.thr = (const uint64_t *)*d_thr;
     out.cmap = T.cmap;
     out.n = T.n;
@@ -342,7 +362,7 @@ bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_
     hipLaunchKernelGGL(s2_hint_kernel, dim3(r2blocks), dim3(256), 0, 0, out, (uint8_t *)*d_lines, chars);
     S2_TRY(hipGetLastError());
     S2_TRY(hipStreamSynchronize(0));
-    bytes = nlines * 128 + (uint64_t)r2 * sizeof(uint64_t) + 2 * (entries ? entries : 1) * sizeof(uint32_t);
+    bytes = nlines * 128 + (2 * (uint64_t)r2 + 4) * sizeof(uint64_t) + 2 * (entries ? entries : 1) * sizeof(uint32_t);
     return true;
 }
 

@@ -19,10 +19,12 @@
 //   d1  I2     refined row holding LF(LF(first position))
 //   d2  O1 | O2 << 16          offsets of those images inside I1 / I2
 //   d3  len16 | char << 16 | col_id << 24        (len <= 65534 by construction)
-//   d4  idx low 32
-//   d5  idx high 8 | char2 << 8 | col_id2 << 16 | hints << 24
+//   d4  len8 of row j+1 | len8 of row j+2 << 8 | mismatch-target distances << 16
+//       (as .z of the one-step layout, device_layout.h)
+//   d5  (spare 8) | char2 << 8 | col_id2 << 16 | hints << 24
 //       char2 / col_id2 = character / col id of the original row every position
 //       of this row maps into (LF_row::character, col_row::col_id of that row).
+// idx2[r2+1]: first BWT position of each refined row (cold; idx2[r2] = n).
 // thr2[r2]: the BWT run's threshold per refined row (compare-hints only).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,7 +41,8 @@ constexpr uint32_t kS2BlockRows = kS2BlockLines * kS2RowsPerLine;     // 320 row
 constexpr uint32_t kS2MaxLen = 65534;                                 // longer rows are cut (legal by B.3)
 
 struct S2Table {
-    const uint8_t *lines;     // ceil((r2 + 1) / 5) + 1 lines of 128 bytes; row r2 is a sentinel (idx = n)
+    const uint8_t *lines;     // ceil((r2 + 1) / 5) + 1 lines of 128 bytes; row r2 is a sentinel
+    const uint64_t *idx;      // r2 + 1
     const uint64_t *thr;      // r2
     const uint32_t *next_tbl; // nblk * sigma : first row >= b * 320 holding c
     const uint32_t *prev_tbl; // nblk * sigma : last row < b * 320 holding c
@@ -73,7 +76,9 @@ __device__ __forceinline__ uint32_t s2_o2(const S2Row &w) { return w.d[2] >> 16;
 __device__ __forceinline__ uint32_t s2_len(const S2Row &w) { return w.d[3] & 0xFFFFu; }
 __device__ __forceinline__ uint32_t s2_char(const S2Row &w) { return (w.d[3] >> 16) & 0xFFu; }
 __device__ __forceinline__ uint32_t s2_cid(const S2Row &w) { return w.d[3] >> 24; }
-__device__ __forceinline__ uint64_t s2_idx(const S2Row &w) { return (uint64_t)w.d[4] | ((uint64_t)(w.d[5] & 0xFFu) << 32); }
+__device__ __forceinline__ uint32_t s2_len8_next1(const S2Row &w) { return w.d[4] & 0xFFu; }
+__device__ __forceinline__ uint32_t s2_len8_next2(const S2Row &w) { return (w.d[4] >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t s2_dist(const S2Row &w, uint32_t slot) { return (w.d[4] >> (16 + 4 * slot)) & 0xFu; }
 __device__ __forceinline__ uint32_t s2_char2(const S2Row &w) { return (w.d[5] >> 8) & 0xFFu; }
 __device__ __forceinline__ uint32_t s2_cid2(const S2Row &w) { return (w.d[5] >> 16) & 0xFFu; }
 __device__ __forceinline__ uint32_t s2_hints(const S2Row &w) { return w.d[5] >> 24; }

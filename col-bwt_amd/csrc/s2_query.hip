@@ -25,7 +25,22 @@ __device__ __forceinline__ void s2_threshold_step(const S2Table &T, const uint8_
     if (cidx == kAbsent) return;  // c occurs nowhere: (interval, offset) unchanged (:533-534)
     uint32_t hint = kHintCompare;
     const uint32_t slot = hint_slot(cidx, s_cmap[s2_char(w)]);
-    if (slot < kHintSlots) hint = (s2_hints(w) >> (2 * slot)) & 3u;
+    if (slot < kHintSlots) {
+        hint = (s2_hints(w) >> (2 * slot)) & 3u;
+        const uint32_t dist = s2_dist(w, slot);
+        if (dist != kDistFar && hint != kHintCompare) {   // decided and close: one load, no scan
+            if (hint == kHintPred) {                      // :565-569
+                i -= dist;
+                w = s2_load(T, i);
+                o = s2_len(w) - 1;                        // LF_table.hpp:282
+            } else {                                      // :552-557
+                i += dist;
+                w = s2_load(T, i);
+                o = 0;
+            }
+            return;
+        }
+    }
     S2Row t;
     if (hint == kHintPred) {
         const uint32_t q = s2_pred_char(T, i, c, cidx, t);      // :562
@@ -39,7 +54,7 @@ __device__ __forceinline__ void s2_threshold_step(const S2Table &T, const uint8_
         if (s != kNone) { i = s; o = 0; w = t; }
         return;
     }
-    const uint64_t pos = s2_idx(w) + o;   // LF_table::to_idx (LF_table.hpp:214-217)
+    const uint64_t pos = T.idx[i] + o;    // LF_table::to_idx (LF_table.hpp:214-217)
     uint64_t thr = T.n;                   // :535
     uint32_t ni = i, no = o;
     S2Row nw = w;
@@ -179,14 +194,26 @@ void s2_query_kernel(S2Table T, const uint8_t *__restrict__ bases, const uint64_
             j = s2_i1(w);
             t = s2_o1(w) + o;
         }
-        // LF_table::LF fast-forward (LF_table.hpp:256-259) over refined rows
+        // LF_table::LF fast-forward (LF_table.hpp:256-259) over refined rows, up to three rows
+        // per memory round trip (a row carries the lengths of the two rows after it)
         w = s2_load(T, j);
-        uint32_t len = s2_len(w);
-        while (t >= len && j < T.r2 - 1) {
+        for (;;) {
+            const uint32_t len = s2_len(w);
+            if (t < len || j >= T.r2 - 1) break;
             t -= len;
-            ++j;
+            uint32_t hop = 1;
+            const uint32_t l1 = s2_len8_next1(w);
+            if (l1 != kLen8Long && t >= l1 && j + 1 < T.r2 - 1) {
+                t -= l1;
+                hop = 2;
+                const uint32_t l2 = s2_len8_next2(w);
+                if (l2 != kLen8Long && t >= l2 && j + 2 < T.r2 - 1) {
+                    t -= l2;
+                    hop = 3;
+                }
+            }
+            j += hop;
             w = s2_load(T, j);
-            len = s2_len(w);
         }
         i = j;
         o = t;

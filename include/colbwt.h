@@ -92,7 +92,9 @@ int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colb
  * pre-images of row boundaries (allowed: the query is a function of BWT
  * positions) so that a row also knows the next step's character / col id and
  * the landing of two LF steps -- one 128-byte line fill serves two bases when
- * the next base matches; about 3x the HBM footprint.  AUTO = engine default. */
+ * the next base matches; about 4x the HBM footprint.  AUTO = the engine's
+ * choice: TWO_STEP when it can be built (fewer than 2^32-1 refined rows, enough
+ * HBM), else ONE_STEP. */
 #define COLBWT_LAYOUT_AUTO 0
 #define COLBWT_LAYOUT_ONE_STEP 1
 #define COLBWT_LAYOUT_TWO_STEP 2
