@@ -159,10 +159,13 @@ def main():
                        if world > 1 else "single GPU",
                        "pipeline_chunks": n_chunks,
                        "index_gen_s": round(t_gen, 2), "index_load_s": round(t_load, 2),
-                       "index_hbm_bytes": int(info.device_bytes)},
+                       "index_hbm_bytes": int(info.device_bytes),
+                       "hbm_layout": "two-step" if info.layout == 2 else "one-step",
+                       "hbm_table_rows": int(info.table_rows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pml_query_kernel<u16>", "avg_launch_ms": avg_launch_ms,
+                         "kernel": ("s2_query_kernel<u16>" if info.layout == 2 else "pml_query_kernel<u16>"),
+                         "avg_launch_ms": avg_launch_ms,
                          "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
                          "bases_per_launch": bases_per_launch},
         }

@@ -61,7 +61,8 @@ def main():
         except Exception:
             pass
     json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
-    q = [d for k, d in summary["kernels"].items() if "pml_query_kernel" in k]
+    q = sorted([d for k, d in summary["kernels"].items() if "query_kernel" in k],
+               key=lambda d: -d.get("total_ns", 0))
     if q and "hbm_bytes_per_launch" in q[0] and len(sys.argv) > 2 and sys.argv[2] == "--set-traffic":
         json.dump({"tag": tag, "hbm_bytes_per_launch": q[0]["hbm_bytes_per_launch"],
                    "hbm_read_bytes_per_launch": q[0]["hbm_read_bytes_per_launch"],
