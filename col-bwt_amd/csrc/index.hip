@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/colbwt.h"
+#include "jump_tables.h"
 #include "query_kernels.h"
 
 namespace colbwt {
@@ -175,21 +176,8 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         HIP_TRY(hipMemcpy(first.data(), d_next_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(last.data(), d_prev_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
         // next[b][c] = first run >= b*B holding c ; prev[b][c] = last run < b*B holding c
-        std::vector<uint32_t> next(tbl_entries), prev(tbl_entries);
-        for (uint32_t c = 0; c < sigma; ++c) {
-            uint32_t carry = kNone;
-            for (uint64_t b = nblk; b-- > 0;) {
-                const uint32_t f = first[b * sigma + c];
-                if (f != kNone) carry = f;
-                next[b * sigma + c] = carry;
-            }
-            carry = kNone;
-            for (uint64_t b = 0; b < nblk; ++b) {
-                prev[b * sigma + c] = carry;
-                const uint32_t l = last[b * sigma + c];
-                if (l != kNone) carry = l;
-            }
-        }
+        std::vector<uint32_t> next, prev;
+        finish_jump_tables(first, last, nblk, sigma, next, prev);
         HIP_TRY(hipMemcpy(d_next_, next.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_prev_, prev.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
     }

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "device_layout.h"
+#include "jump_tables.h"
 #include "lf_device.h"
 #include "query_kernels.h"
 #include "s2_layout.h"
@@ -341,21 +342,10 @@ bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_
                        (uint32_t *)*d_prev);
     S2_TRY(hipStreamSynchronize(0));
     {
-        std::vector<uint32_t> first(entries), last(entries), next(entries), prev(entries);
+        std::vector<uint32_t> first(entries), last(entries), next, prev;
         S2_TRY(hipMemcpy(first.data(), *d_next, entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
         S2_TRY(hipMemcpy(last.data(), *d_prev, entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (uint32_t c = 0; c < out.sigma; ++c) {
-            uint32_t carry = kNone;
-            for (uint64_t b = out.nblk; b-- > 0;) {
-                if (first[b * out.sigma + c] != kNone) carry = first[b * out.sigma + c];
-                next[b * out.sigma + c] = carry;
-            }
-            carry = kNone;
-            for (uint64_t b = 0; b < out.nblk; ++b) {
-                prev[b * out.sigma + c] = carry;
-                if (last[b * out.sigma + c] != kNone) carry = last[b * out.sigma + c];
-            }
-        }
+        finish_jump_tables(first, last, out.nblk, out.sigma, next, prev);
         S2_TRY(hipMemcpy(*d_next, next.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
         S2_TRY(hipMemcpy(*d_prev, prev.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
     }

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "device_layout.h"
+#include "lane_io.h"
 #include "lf_device.h"
 #include "query_kernels.h"
 #include "s2_layout.h"
@@ -69,62 +70,6 @@ __device__ __forceinline__ void s2_threshold_step(const S2Table &T, const uint8_
 
 namespace {
 
-constexpr uint32_t kFlush2 = 16;
-
-// PML u16 / col id u8 of 16 bases collected in registers (see query_kernels.hip).
-struct Acc16 {
-    uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, c0 = 0, c1 = 0;
-    uint32_t cnt = 0;
-    __device__ __forceinline__ void push(uint32_t L, uint32_t cid) {
-        p3 = (p3 << 16) | (p2 >> 48);
-        p2 = (p2 << 16) | (p1 >> 48);
-        p1 = (p1 << 16) | (p0 >> 48);
-        p0 = (p0 << 16) | (uint64_t)(L & 0xFFFFu);
-        c1 = (c1 << 8) | (c0 >> 56);
-        c0 = (c0 << 8) | (uint64_t)cid;
-        ++cnt;
-    }
-    __device__ __forceinline__ void flush(uint16_t *pml, uint8_t *cid, uint64_t g) {
-        if (cnt == kFlush2) {
-            uint4 *dst = reinterpret_cast<uint4 *>(pml + g);
-            dst[0] = make_uint4((uint32_t)p0, (uint32_t)(p0 >> 32), (uint32_t)p1, (uint32_t)(p1 >> 32));
-            dst[1] = make_uint4((uint32_t)p2, (uint32_t)(p2 >> 32), (uint32_t)p3, (uint32_t)(p3 >> 32));
-            *reinterpret_cast<uint4 *>(cid + g) =
-                make_uint4((uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32));
-        } else {
-            for (uint32_t e = 0; e < cnt; ++e) {
-                pml[g + e] = (uint16_t)p0;
-                cid[g + e] = (uint8_t)c0;
-                p0 = (p0 >> 16) | (p1 << 48);
-                p1 = (p1 >> 16) | (p2 << 48);
-                p2 = (p2 >> 16) | (p3 << 48);
-                p3 >>= 16;
-                c0 = (c0 >> 8) | (c1 << 56);
-                c1 >>= 8;
-            }
-        }
-        cnt = 0;
-    }
-};
-
-__device__ __forceinline__ void rd_refill(uint32_t (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(bases + (g & ~(uint64_t)63));
-    uint4 v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = src[q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        s_rd[4 * q + 0][threadIdx.x] = v[q].x;
-        s_rd[4 * q + 1][threadIdx.x] = v[q].y;
-        s_rd[4 * q + 2][threadIdx.x] = v[q].z;
-        s_rd[4 * q + 3][threadIdx.x] = v[q].w;
-    }
-}
-__device__ __forceinline__ uint32_t rd_get(uint32_t (*s_rd)[kQueryBlock], uint64_t g) {
-    const uint32_t b = (uint32_t)g & 63u;
-    return (s_rd[b >> 2][threadIdx.x] >> (8 * (b & 3u))) & 0xFFu;
-}
-
 template <typename PmlT>
 __global__ __launch_bounds__(kQueryBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
 void s2_query_kernel(S2Table T, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off,
@@ -148,8 +93,9 @@ void s2_query_kernel(S2Table T, const uint8_t *__restrict__ bases, const uint64_
     S2Row w = s2_load(T, i);
     uint32_t o = s2_len(w) - 1;
     uint32_t L = 0;
-    Acc16 acc;
-    rd_refill(s_rd, bases, off + m - 1);
+    OutAcc<PmlT> acc;
+    ReadWindow win;
+    win.refill(s_rd, bases, off + m - 1);
 
     auto emit = [&](uint64_t g, uint32_t len, uint32_t col_id, bool last) {   // :525
         if constexpr (kWide) {
@@ -157,13 +103,13 @@ void s2_query_kernel(S2Table T, const uint8_t *__restrict__ bases, const uint64_
             cid[g] = (uint8_t)col_id;
         } else {
             acc.push(len, col_id);
-            if ((g & (kFlush2 - 1)) == 0 || last) acc.flush(reinterpret_cast<uint16_t *>(pml), cid, g);
+            if ((g & (kFlush - 1)) == 0 || last) acc.flush(pml, cid, g);
         }
     };
 
     for (uint64_t k = m; k > 0;) {
         const uint64_t g = off + k - 1;
-        const uint32_t c = rd_get(s_rd, g);              // :512 pattern[m-i-1], raw byte
+        const uint32_t c = win.get(s_rd, g);              // :512 pattern[m-i-1], raw byte
         const uint32_t col_id = s2_cid(w);               // :513 before any re-orientation
         if (s2_char(w) == c) {                           // :516
             ++L;
@@ -174,20 +120,20 @@ void s2_query_kernel(S2Table T, const uint8_t *__restrict__ bases, const uint64_
         --k;
         emit(g, L, col_id, k == 0);
         if (k == 0) break;                               // the last LF (:527) has no observable effect
-        if ((g & 63) == 0) rd_refill(s_rd, bases, g - 1);
+        if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
 
         // One LF step (:527) lands every position of this refined row in the same original
         // row, whose character / col id are char2 / cid2.  If the next base matches it,
         // the next iteration would be ++length with that col id (:513-517) followed by
         // another LF: emit it here and jump LF o LF in one go.
         uint32_t j, t;
-        const uint32_t c2 = rd_get(s_rd, g - 1);
+        const uint32_t c2 = win.get(s_rd, g - 1);
         if (c2 == s2_char2(w)) {
             ++L;
             --k;
             emit(g - 1, L, s2_cid2(w), k == 0);
             if (k == 0) break;
-            if (((g - 1) & 63) == 0) rd_refill(s_rd, bases, g - 2);
+            if (((g - 1) & 63) == 0) win.refill(s_rd, bases, g - 2);
             j = s2_i2(w);
             t = s2_o2(w) + o;
         } else {
