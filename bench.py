@@ -160,11 +160,11 @@ def main():
                        "pipeline_chunks": n_chunks,
                        "index_gen_s": round(t_gen, 2), "index_load_s": round(t_load, 2),
                        "index_hbm_bytes": int(info.device_bytes),
-                       "hbm_layout": "two-step" if info.layout == 2 else "one-step",
+                       "hbm_layout": {1: "one-step", 2: "two-step", 3: "three-step"}.get(info.layout, "?"),
                        "hbm_table_rows": int(info.table_rows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("s2_query_kernel<u16>" if info.layout == 2 else "pml_query_kernel<u16>"),
+                         "kernel": (f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>"),
                          "avg_launch_ms": avg_launch_ms,
                          "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
                          "bases_per_launch": bases_per_launch},

@@ -114,7 +114,7 @@ class ColPml:
 
     @classmethod
     def load(cls, prefix_or_file, device=0, layout=0):
-        """layout: 0 = engine default, 1 = one-step rows, 2 = two-step rows (same results)."""
+        """layout: 0 = engine default, 1 = one-step rows, 2 / 3 = K-step rows (same results)."""
         h = C.c_void_p()
         _check(lib().colbwt_index_open_layout(os.fsencode(prefix_or_file), None, int(device), int(layout),
                                               C.byref(h)))

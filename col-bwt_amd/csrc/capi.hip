@@ -23,7 +23,7 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_TWO_STEP
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_THREE_STEP
 
 struct colbwt_index {
     Index ix;
@@ -140,8 +140,8 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         API_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     API_HIP(hipEventRecord(ev[1], stream));
-    if (idx->ix.layout() == 2)
-        launch_s2_query(idx->ix.table2(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    if (idx->ix.layout() >= 2)
+        launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     API_HIP(hipGetLastError());
@@ -184,7 +184,7 @@ const char *colbwt_last_error(void) { return g_err.c_str(); }
 
 static int default_layout() {
     const char *e = getenv("COLBWT_LAYOUT");   // experiment override: 1 = one-step, 2 = two-step
-    if (e && (e[0] == '1' || e[0] == '2') && e[1] == 0) return e[0] - '0';
+    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) return e[0] - '0';
     return COLBWT_LAYOUT_DEFAULT_CHOICE;
 }
 
@@ -198,7 +198,7 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     if (!out) return fail(COLBWT_ERR_ARG, "null out");
     const bool automatic = layout == COLBWT_LAYOUT_AUTO;
     if (automatic) layout = default_layout();
-    if (layout != COLBWT_LAYOUT_ONE_STEP && layout != COLBWT_LAYOUT_TWO_STEP) return fail(COLBWT_ERR_ARG, "bad layout");
+    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_THREE_STEP) return fail(COLBWT_ERR_ARG, "bad layout");
     *out = nullptr;
     if (!widths_ok(widths))
         return fail(COLBWT_ERR_ARG, "only the shipped widths BWT_BYTES=5 RUN_BYTES=4 LEN_BYTES=2 ID_BITS=8 are supported");
@@ -206,9 +206,10 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
     int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
-    if (rc == COLBWT_ERR_NOMEM && automatic && layout == COLBWT_LAYOUT_TWO_STEP) {
-        // the two-step table does not fit (HBM, or more than 2^32-2 refined rows): one-step rows
-        rc = idx->ix.load((const uint8_t *)bytes, len, device, COLBWT_LAYOUT_ONE_STEP, err);
+    while (rc == COLBWT_ERR_NOMEM && automatic && layout > COLBWT_LAYOUT_ONE_STEP) {
+        // the K-step table does not fit (HBM, or more than 2^32-2 refined rows): one step fewer
+        --layout;
+        rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
     }
     if (rc != COLBWT_OK) {
         delete idx;
@@ -292,8 +293,8 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
         API_HIP(hipEventCreate(&e1));
         API_HIP(hipEventRecord(e0, stream));
     }
-    if (idx->ix.layout() == 2)
-        launch_s2_query(idx->ix.table2(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+    if (idx->ix.layout() >= 2)
+        launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     API_HIP(hipGetLastError());

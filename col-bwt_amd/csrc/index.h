@@ -7,7 +7,8 @@
 #include <string>
 
 #include "device_layout.h"
-#include "s2_layout.h"
+#include "query_kernels.h"
+#include "sk_layout.h"
 
 namespace colbwt {
 
@@ -25,13 +26,13 @@ public:
 
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
-    // layout: 1 = one-step (device_layout.h), 2 = two-step (s2_layout.h, built on top of 1).
+    // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1).
     int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err);
 
     const DevTable &table() const { return tbl_; }
-    const S2Table &table2() const { return tbl2_; }
+    const SKTable &table_k() const { return tblk_; }
     int layout() const { return layout_; }
-    uint64_t table_rows() const { return layout_ == 2 ? tbl2_.r2 : tbl_.r; }
+    uint64_t table_rows() const { return layout_ >= 2 ? tblk_.r : tbl_.r; }
     int device() const { return device_; }
     uint64_t bwt_r() const { return bwt_r_; }
     uint64_t n() const { return tbl_.n; }
@@ -42,9 +43,9 @@ public:
 private:
     void release();
     DevTable tbl_{};
-    S2Table tbl2_{};
+    SKTable tblk_{};
+    SKBuffers bufk_;
     int layout_ = 1;
-    void *d2_lines_ = nullptr, *d2_idx_ = nullptr, *d2_thr_ = nullptr, *d2_next_ = nullptr, *d2_prev_ = nullptr;
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t device_bytes_ = 0;

@@ -49,10 +49,11 @@ Index::~Index() { release(); }
 
 void Index::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_, &d2_lines_, &d2_idx_, &d2_thr_, &d2_next_, &d2_prev_}) {
+    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    bufk_.release();
     device_bytes_ = 0;
 }
 
@@ -204,16 +205,15 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         HIP_TRY(hipStreamSynchronize(0));
         tbl_.use_hints = 1;
 
-        // ---- optional two-step layout on top (s2_layout.h)
+        // ---- optional K-step layout on top (sk_layout.h)
         layout_ = 1;
-        if (layout == 2) {
-            uint64_t bytes2 = 0;
-            if (!build_s2(tbl_, hc, tbl2_, &d2_lines_, &d2_idx_, &d2_thr_, &d2_next_, &d2_prev_, bytes2, err)) {
+        if (layout == 2 || layout == 3) {
+            if (!build_sk(tbl_, hc, layout, tblk_, bufk_, err)) {
                 release();
                 return COLBWT_ERR_NOMEM;
             }
-            device_bytes_ += bytes2;
-            layout_ = 2;
+            device_bytes_ += bufk_.bytes;
+            layout_ = layout;
         }
     }
     return COLBWT_OK;

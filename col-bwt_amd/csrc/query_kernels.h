@@ -18,11 +18,11 @@ void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t 
 }  // namespace colbwt
 #include <string>
 
-#include "s2_layout.h"
+#include "sk_layout.h"
 namespace colbwt {
 
-// The same query over the two-step layout (s2_query.hip).
-void launch_s2_query(const S2Table &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+// The same query over a K-step layout (sk_query.hip); K = T.steps.
+void launch_sk_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                      void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
 
 // ---- load-time kernels (index_kernels.hip) --------------------------------
@@ -47,9 +47,15 @@ struct HintChars {
 };
 void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream);
 
-// Two-step layout from the one-step tables (s2_build.hip); false + err when it cannot be built.
-bool build_s2(const DevTable &T, const HintChars &chars, S2Table &out, void **d_lines, void **d_idx, void **d_thr,
-              void **d_next, void **d_prev, uint64_t &bytes, std::string &err);
+// Device allocations of one K-step table.
+struct SKBuffers {
+    void *lines = nullptr, *idx = nullptr, *thr = nullptr, *next = nullptr, *prev = nullptr;
+    uint64_t bytes = 0;
+    void release();
+};
+// K-step layout (steps = 2 or 3) from the one-step tables (sk_build.hip); false + err when it
+// cannot be built (more than 2^32-2 rows, out of memory).
+bool build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err);
 
 // Backward-walk read sampler (synthetic benchmark input).
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,

@@ -59,7 +59,7 @@ typedef struct colbwt_info {
     uint32_t sigma;        /* distinct characters present in the table */
     uint32_t device;       /* HIP device ordinal                       */
     uint64_t device_bytes; /* HBM held by the index                    */
-    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_STEP       */
+    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ */
     uint32_t reserved_;
     uint64_t table_rows;   /* rows of the HBM table actually queried   */
 } colbwt_info;
@@ -88,16 +88,17 @@ int colbwt_index_open(const char *prefix_or_file, const colbwt_widths *widths, i
 int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,
                              int device, colbwt_index **out);
 /* HBM table layouts (results are identical).  ONE_STEP:
- * 16-byte rows, one LF step per row load.  TWO_STEP: rows split at the
- * pre-images of row boundaries (allowed: the query is a function of BWT
- * positions) so that a row also knows the next step's character / col id and
- * the landing of two LF steps -- one 128-byte line fill serves two bases when
- * the next base matches; about 4x the HBM footprint.  AUTO = the engine's
- * choice: TWO_STEP when it can be built (fewer than 2^32-1 refined rows, enough
- * HBM), else ONE_STEP. */
+ * 16-byte rows, one LF step per row load.  TWO_STEP / THREE_STEP: rows split at
+ * the pre-images of row boundaries (allowed: the query is a function of BWT
+ * positions) so that a row also knows the characters / col ids of the next one /
+ * two steps and the landings of LF^2 / LF^3 -- one 128-byte line fill serves up
+ * to K bases while the read keeps matching; about 4x / 7x the HBM footprint.
+ * AUTO = the engine's choice: the deepest layout that can be built (fewer than
+ * 2^32-1 refined rows, enough HBM). */
 #define COLBWT_LAYOUT_AUTO 0
 #define COLBWT_LAYOUT_ONE_STEP 1
 #define COLBWT_LAYOUT_TWO_STEP 2
+#define COLBWT_LAYOUT_THREE_STEP 3
 int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
                              colbwt_index **out);
 int colbwt_index_open_memory_layout(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,

@@ -31,7 +31,7 @@ def check(image, reads, label, wide=False):
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
     epml, ecid = ref.query_batch(bases, off, wide=wide)
-    for layout in (1, 2):            # one-step rows / two-step refined rows: identical results
+    for layout in (1, 2, 3):         # one-step rows / K-step refined rows: identical results
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
         assert tbl.info().layout == layout
         pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
@@ -39,7 +39,7 @@ def check(image, reads, label, wide=False):
         assert np.array_equal(cid, ecid), f"{label}/L{layout}: CID differs at {np.flatnonzero(cid != ecid)[:5]}"
         rows2 = tbl.info().table_rows
         tbl.close()
-    print(f"ok {label}: {len(reads)} reads, {int(off[-1])} bases (two-step table: {rows2} rows)")
+    print(f"ok {label}: {len(reads)} reads, {int(off[-1])} bases (three-step table: {rows2} rows)")
 
 
 def rand_reads(rng, n, lo, hi, alphabet=b"ACGT"):

@@ -30,7 +30,7 @@ def _check(pkg, oracle, image, reads, wide=False):
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
     epml, ecid = ref.query_batch(bases, off, wide=wide, threads=8)
-    for layout in (1, 2):     # one-step rows and two-step refined rows must both be bit-exact
+    for layout in (1, 2, 3):  # one-step rows and K-step refined rows must all be bit-exact
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
         assert tbl.info().layout == layout
         pml, cid, st = tbl.query_batch(bases, off, wide=wide)
@@ -218,7 +218,7 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
     assert 0.02 < resets < 0.6          # the recipe's mix of extends and resets
 
 
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [1, 2, 3])
 def test_full_scale_properties(pkg, oracle, layout):
     """BASELINE config C2 scale (2e8 rows): size-independent properties --
     idempotence (two runs, identical bytes), batch-position independence (a
