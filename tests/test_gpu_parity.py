@@ -323,3 +323,19 @@ def test_concurrent_host_threads_share_one_index(pkg, oracle):
     for t in range(4):
         ep, ec = ref.query_batch(*jobs[t], threads=8)
         assert np.array_equal(results[t][0], ep) and np.array_equal(results[t][1], ec)
+
+
+def test_open_close_does_not_leak_hbm(pkg):
+    """Index::release frees every table of every layout (incl. the temporary
+    level the three-step build refines from)."""
+    import torch
+    image = pkg.synth_index(1_000_000, mean_len=8, split_permille=0, seed=5)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for layout in (1, 2, 3, 0) * 3:
+        tbl = pkg.ColPml.from_bytes(image, layout=layout)
+        assert tbl.info().device_bytes > 0
+        tbl.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < 64 << 20, f"HBM leak: {free0 - free1} bytes"

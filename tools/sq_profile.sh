@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/sq_${1:-a}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for LAY in 1 2; do
+for LAY in ${LAYOUTS:-1 2 3}; do
   export COLBWT_LAYOUT=$LAY
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/l$LAY" -o b -- python3 "$REPO/bench.py" --no-cpu --steps 1 --warmup 0 > "$OUT/l$LAY.json" 2> "$OUT/l$LAY.err"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD --output-format csv -d "$OUT/m$LAY" -o b -- python3 "$REPO/bench.py" --no-cpu --steps 1 --warmup 0 > "$OUT/m$LAY.json" 2> "$OUT/m$LAY.err"
