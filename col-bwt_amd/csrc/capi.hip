@@ -183,7 +183,7 @@ const char *colbwt_version(void) { return "colbwt-mi355x 0.1.0 (gfx950)"; }
 const char *colbwt_last_error(void) { return g_err.c_str(); }
 
 static int default_layout() {
-    const char *e = getenv("COLBWT_LAYOUT");   // experiment override: 1 = one-step, 2 = two-step
+    const char *e = getenv("COLBWT_LAYOUT");   // override: 1 = one-step, 2 / 3 = K-step rows
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) return e[0] - '0';
     return COLBWT_LAYOUT_DEFAULT_CHOICE;
 }
