@@ -16,3 +16,14 @@ def test_emulated_kernels_match_oracle_under_asan():
     out = subprocess.run([sys.executable, os.path.join(emu, "run_emu_checks.py")], env=env,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "EMU-ALL-OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_emulated_kernels_fuzz_all_layouts():
+    """Random tables (alphabet 2..9, very long rows, sub-run splits) x random / walk reads, layouts 1-3."""
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-C", emu, "libcolbwt_emu.so"], stdout=subprocess.DEVNULL)
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+    out = subprocess.run([sys.executable, os.path.join(emu, "fuzz_emu.py"), "0", "10"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "FUZZ-OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]

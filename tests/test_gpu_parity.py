@@ -339,3 +339,29 @@ def test_open_close_does_not_leak_hbm(pkg):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < 64 << 20, f"HBM leak: {free0 - free1} bytes"
+
+
+@pytest.mark.parametrize("seed0", [0, 100])
+def test_fuzz_random_tables_all_layouts(pkg, oracle, seed0):
+    """Randomised sweep: alphabets of 2..9 arbitrary bytes, run lengths 1..300 with a few rows
+    beyond the 16-bit length field, sub-run splits, arbitrary thresholds; random + walk reads."""
+    for seed in range(seed0, seed0 + 25):
+        rng = np.random.default_rng(seed)
+        sigma = int(rng.integers(2, 10))
+        alpha = bytes(rng.choice(np.arange(1, 128), size=sigma, replace=False).astype(np.uint8).tolist())
+        r = int(rng.integers(3, 40_000))
+        img = helpers.random_table(rng, r, alphabet=alpha, max_len=int(rng.choice([1, 2, 9, 40, 300])),
+                                   split_prob=float(rng.choice([0, 0.1, 0.5])))
+        if seed % 4 == 0:
+            t = helpers.unpack_col_pml(img)
+            lens = np.diff(np.append(t["idx"].astype(np.int64), t["n"]))
+            lens[rng.integers(0, r, size=3)] = rng.integers(65530, 200000, size=3)
+            idx = np.concatenate(([0], np.cumsum(lens)[:-1]))
+            n = int(lens.sum())
+            itv, off = helpers.lf_columns(t["char"], idx, n)
+            img = helpers.pack_col_pml(int(t["bwt_r"]), n, t["char"], idx, itv, off & np.uint64(0xFFFF), t["cid"],
+                                       rng.integers(0, n, size=r))
+        img = bytes(img)
+        reads = _rand_reads(rng, 300, 0, 200, alphabet=alpha + b"\xfe")
+        reads += helpers.backward_walk_reads(img, 300, int(rng.integers(1, 400)), 0.02, seed=seed)
+        _check(pkg, oracle, img, reads)
