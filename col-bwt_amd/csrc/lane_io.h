@@ -33,12 +33,26 @@ struct ReadWindow {
 
 // Output collector: kFlush = 16 bases per flush, flush boundaries at global
 // element indices that are multiples of 16, so a full flush is aligned vector
-// stores covering whole 32-byte sectors; partial groups (read ends) go out
-// element by element.
+// stores covering whole 32-byte sectors; partial groups (read ends) go out in
+// power-of-two pieces.  The group at the START of a read is flushed after the
+// kernel's loop, where the wave has reconverged (inside the loop every lane
+// would run it alone, in the trip its own read ends).
 constexpr uint32_t kFlush = 16;
 
 template <typename PmlT>
 struct OutAcc;
+
+struct U128 {
+    uint64_t lo, hi;
+};
+// store of a value at an address that is only aligned for the array's element type
+template <typename V, typename E>
+__device__ __forceinline__ void put(E *dst, V v) {
+    struct __attribute__((packed, aligned(alignof(E)))) Slot {
+        V v;
+    };
+    reinterpret_cast<Slot *>(dst)->v = v;
+}
 
 template <>
 struct OutAcc<uint16_t> {
@@ -61,15 +75,30 @@ struct OutAcc<uint16_t> {
             *reinterpret_cast<uint4 *>(cid + g) =
                 make_uint4((uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32));
         } else {
-            for (uint32_t e = 0; e < cnt; ++e) {
-                pml[g + e] = (uint16_t)p0;
-                cid[g + e] = (uint8_t)c0;
-                p0 = (p0 >> 16) | (p1 << 48);
-                p1 = (p1 >> 16) | (p2 << 48);
-                p2 = (p2 >> 16) | (p3 << 48);
-                p3 >>= 16;
-                c0 = (c0 >> 8) | (c1 << 56);
-                c1 >>= 8;
+            // read ends: 8 + 4 + 2 + 1 elements, each piece one (unaligned) store per array
+            uint16_t *dp = pml + g;
+            uint8_t *dc = cid + g;
+            if (cnt & 8u) {
+                put(dp, U128{p0, p1});
+                put(dc, c0);
+                p0 = p2; p1 = p3; c0 = c1;
+                dp += 8; dc += 8;
+            }
+            if (cnt & 4u) {
+                put(dp, p0);
+                put(dc, (uint32_t)c0);
+                p0 = p1; c0 >>= 32;
+                dp += 4; dc += 4;
+            }
+            if (cnt & 2u) {
+                put(dp, (uint32_t)p0);
+                put(dc, (uint16_t)c0);
+                p0 >>= 32; c0 >>= 16;
+                dp += 2; dc += 2;
+            }
+            if (cnt & 1u) {
+                *dp = (uint16_t)p0;
+                *dc = (uint8_t)c0;
             }
         }
         cnt = 0;
@@ -80,6 +109,129 @@ template <>
 struct OutAcc<uint32_t> {  // reads longer than 65535 bases: wide PML, stored per base
     __device__ __forceinline__ void push(uint32_t, uint32_t) {}
     __device__ __forceinline__ void flush(uint32_t *, uint8_t *, uint64_t) {}
+};
+
+// ---- wave-synchronous variants (sk_query.hip) --------------------------------------
+// A vector-memory instruction occupies the CU's address / tag pipeline for about as long
+// with one active lane as with 64, and the query kernels are bound by exactly that pipeline
+// (DESIGN.md 4.1).  So both streams below touch memory only at the top of a loop trip,
+// where the wave is converged: one instruction then serves every lane that needs it.
+
+// Read bytes: a 64-byte window per lane that slides down the read.  It is refilled for ALL
+// lanes of the wave whenever ANY lane is about to run out (each lane at its own position:
+// 4 x 16 bytes ending just above its next base), i.e. 3-4 times per 150-base read and wave
+// instead of once per lane and 64 bases.
+struct SlidingWindow {
+    uint32_t wb;   // low 32 bits of the global index of the window's first byte
+    __device__ __forceinline__ void init(uint64_t g) { wb = (uint32_t)g + 1u; }   // nothing buffered
+    // bytes buffered at and below global index g
+    __device__ __forceinline__ uint32_t avail(uint64_t g) const { return (uint32_t)g - wb + 1u; }
+    __device__ __forceinline__ void refill(uint32_t (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
+        const uint64_t a = g >= 60 ? (g - 60) & ~(uint64_t)3 : 0;   // dword aligned; [a, a + 64) holds g
+        struct __attribute__((packed, aligned(4))) Q {
+            uint32_t x, y, z, w;
+        };
+        const Q *src = reinterpret_cast<const Q *>(bases + a);
+        Q v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = src[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s_rd[4 * q + 0][threadIdx.x] = v[q].x;
+            s_rd[4 * q + 1][threadIdx.x] = v[q].y;
+            s_rd[4 * q + 2][threadIdx.x] = v[q].z;
+            s_rd[4 * q + 3][threadIdx.x] = v[q].w;
+        }
+        wb = (uint32_t)a;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t (*s_rd)[kQueryBlock], uint64_t g) const {
+        const uint32_t b = ((uint32_t)g - wb) & 63u;
+        return (s_rd[b >> 2][threadIdx.x] >> (8 * (b & 3u))) & 0xFFu;
+    }
+};
+
+// Outputs: room for 18 elements, so that up to 3 values can be pushed per trip and the
+// aligned 16-element group they complete is stored by the ONE flush at the top of the next
+// trip (element 0 = lowest address = newest).
+struct OutAcc18 {
+    uint64_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, c0 = 0, c1 = 0;
+    uint32_t p4 = 0, c2 = 0;
+    uint32_t cnt = 0;
+    __device__ __forceinline__ void push(uint32_t L, uint32_t cid) {
+        p4 = (p4 << 16) | (uint32_t)(p3 >> 48);
+        p3 = (p3 << 16) | (p2 >> 48);
+        p2 = (p2 << 16) | (p1 >> 48);
+        p1 = (p1 << 16) | (p0 >> 48);
+        p0 = (p0 << 16) | (uint64_t)(L & 0xFFFFu);
+        c2 = (c2 << 8) | (uint32_t)(c1 >> 56);
+        c1 = (c1 << 8) | (c0 >> 56);
+        c0 = (c0 << 8) | (uint64_t)cid;
+        ++cnt;
+    }
+    // n < 16 elements (q0.. / d0..) to dp / dc: 8 + 4 + 2 + 1, one store per piece and array
+    static __device__ __forceinline__ void pieces(uint16_t *dp, uint8_t *dc, uint32_t n, uint64_t q0, uint64_t q1,
+                                                  uint64_t q2, uint64_t q3, uint64_t d0, uint64_t d1) {
+        if (n & 8u) {
+            put(dp, U128{q0, q1});
+            put(dc, d0);
+            q0 = q2; q1 = q3; d0 = d1;
+            dp += 8; dc += 8;
+        }
+        if (n & 4u) {
+            put(dp, q0);
+            put(dc, (uint32_t)d0);
+            q0 = q1; d0 >>= 32;
+            dp += 4; dc += 4;
+        }
+        if (n & 2u) {
+            put(dp, (uint32_t)q0);
+            put(dc, (uint16_t)d0);
+            q0 >>= 32; d0 >>= 16;
+            dp += 2; dc += 2;
+        }
+        if (n & 1u) {
+            *dp = (uint16_t)q0;
+            *dc = (uint8_t)d0;
+        }
+    }
+    // gl = global index of element 0.  If the collector holds an element on a 16-boundary,
+    // the group from that boundary up is complete: store it, keep the elements below it.
+    __device__ __forceinline__ void flush_group(uint16_t *pml, uint8_t *cid, uint64_t gl) {
+        const uint32_t extra = (0u - (uint32_t)gl) & (kFlush - 1);   // elements below the boundary (<= 2)
+        if (extra >= cnt) return;
+        const bool s1 = extra & 1u, s2 = extra & 2u;
+        uint64_t a0 = s1 ? (p0 >> 16) | (p1 << 48) : p0;
+        uint64_t a1 = s1 ? (p1 >> 16) | (p2 << 48) : p1;
+        uint64_t a2 = s1 ? (p2 >> 16) | (p3 << 48) : p2;
+        uint64_t a3 = s1 ? (p3 >> 16) | ((uint64_t)p4 << 48) : p3;
+        const uint64_t a4 = s1 ? p4 >> 16 : p4;
+        a0 = s2 ? (a0 >> 32) | (a1 << 32) : a0;
+        a1 = s2 ? (a1 >> 32) | (a2 << 32) : a1;
+        a2 = s2 ? (a2 >> 32) | (a3 << 32) : a2;
+        a3 = s2 ? (a3 >> 32) | (a4 << 32) : a3;
+        uint64_t b0 = s1 ? (c0 >> 8) | (c1 << 56) : c0;
+        uint64_t b1 = s1 ? (c1 >> 8) | ((uint64_t)c2 << 56) : c1;
+        const uint64_t b2 = s1 ? c2 >> 8 : c2;
+        b0 = s2 ? (b0 >> 16) | (b1 << 48) : b0;
+        b1 = s2 ? (b1 >> 16) | (b2 << 48) : b1;
+        const uint32_t n = cnt - extra;
+        const uint64_t g = gl + extra;
+        if (n == kFlush) {
+            uint4 *dst = reinterpret_cast<uint4 *>(pml + g);
+            dst[0] = make_uint4((uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32));
+            dst[1] = make_uint4((uint32_t)a2, (uint32_t)(a2 >> 32), (uint32_t)a3, (uint32_t)(a3 >> 32));
+            *reinterpret_cast<uint4 *>(cid + g) =
+                make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+        } else {
+            pieces(pml + g, cid + g, n, a0, a1, a2, a3, b0, b1);   // the group at the END of the read
+        }
+        cnt = extra;
+    }
+    // what is left when the read is done (its first bases, below the last boundary)
+    __device__ __forceinline__ void flush_rest(uint16_t *pml, uint8_t *cid, uint64_t gl) {
+        if (cnt) pieces(pml + gl, cid + gl, cnt, p0, p1, p2, p3, c0, c1);
+        cnt = 0;
+    }
 };
 
 }  // namespace colbwt

@@ -155,7 +155,7 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
             cid[g] = (uint8_t)col_id;
         } else {
             acc.push(L, col_id);
-            if ((g & (kFlush - 1)) == 0 || k == 0) acc.flush(pml, cid, g);
+            if ((g & (kFlush - 1)) == 0) acc.flush(pml, cid, g);
         }
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
         if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
@@ -185,6 +185,9 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
         }
         i = j;
         o = t;
+    }
+    if constexpr (!kWide) {
+        if (acc.cnt) acc.flush(pml, cid, off);       // the group at the start of the read
     }
 }
 

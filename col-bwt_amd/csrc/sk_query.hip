@@ -21,31 +21,13 @@
 
 namespace colbwt {
 
-// col_pml::threshold_step (col_bwt.hpp:531-574) over level-K rows; see
-// query_kernels.hip for the hint / distance logic.
+// The part of col_pml::threshold_step (col_bwt.hpp:531-574) the kernel cannot turn into
+// a single row load: the target is far away (scan, then the jump tables) or the row's
+// hint says the threshold falls inside the row (compare positions, :560).  cidx is the
+// dense index of c (present in the BWT); see query_kernels.hip for the hint logic.
 template <int K>
-__device__ __forceinline__ void sk_threshold_step(const SKTable &T, const uint8_t *s_cmap, uint32_t &i, uint32_t &o,
-                                                  SKRow<K> &w, uint32_t c) {
-    const uint32_t cidx = s_cmap[c];
-    if (cidx == kAbsent) return;  // c occurs nowhere: (interval, offset) unchanged (:533-534)
-    uint32_t hint = kHintCompare;
-    const uint32_t slot = hint_slot(cidx, s_cmap[sk_char<K>(w)]);
-    if (slot < kHintSlots) {
-        hint = (sk_hints<K>(w) >> (2 * slot)) & 3u;
-        const uint32_t dist = sk_dist<K>(w, slot);
-        if (dist != kSKDistFar && hint != kHintCompare) { // decided and close: one load, no scan
-            if (hint == kHintPred) {                      // :565-569
-                i -= dist;
-                w = sk_load<K>(T, i);
-                o = sk_len<K>(w) - 1;                     // LF_table.hpp:282
-            } else {                                      // :552-557
-                i += dist;
-                w = sk_load<K>(T, i);
-                o = 0;
-            }
-            return;
-        }
-    }
+__device__ __forceinline__ void sk_threshold_scan(const SKTable &T, uint32_t &i, uint32_t &o, SKRow<K> &w, uint32_t c,
+                                               uint32_t cidx, uint32_t hint) {
     SKRow<K> t;
     if (hint == kHintPred) {
         const uint32_t q = sk_pred_char<K>(T, i, c, cidx, t);      // :562
@@ -74,6 +56,18 @@ __device__ __forceinline__ void sk_threshold_step(const SKTable &T, const uint8_
 
 namespace {
 
+// What the row being loaded is for travels in the offset register: an LF landing still to be
+// placed carries its offset (< 2^17), the other arrivals one of these codes.
+constexpr uint32_t kOffLastPos = 0xFFFFFFFFu;   // LF-style arrival, offset clamped to the row's last position
+constexpr uint32_t kOffPred = 0xFFFFFFFEu;      // threshold target reached from below: offset = len - 1
+constexpr uint32_t kOffSucc = 0xFFFFFFFDu;      // threshold target reached from above: offset = 0
+
+// One row load per loop trip.  A lane's work is a chain of dependent row loads
+// (LF landing, fast-forward hop, threshold target); the wave pays one memory
+// round trip per LOAD SITE it passes, so all three kinds share the single load
+// at the top of the loop and each lane spends the trip on whatever its own
+// chain needs next.  A wave then runs for max-over-lanes(loads of the lane)
+// round trips instead of iterations x (LF + hops + threshold) round trips.
 template <int K, typename PmlT>
 __global__ __launch_bounds__(kQueryBlock) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
 void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off,
@@ -92,39 +86,82 @@ void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_
     const uint64_t m = read_off[rd + 1] - off;
     if (m == 0) return;
 
-    // col_bwt.hpp:503-508: pos = n-1 = the last position of the last row
-    uint32_t i = T.r - 1;
-    SKRow<K> w = sk_load<K>(T, i);
-    uint32_t o = sk_len<K>(w) - 1;
-    uint32_t L = 0;
-    OutAcc<PmlT> acc;
-    ReadWindow win;
-    win.refill(s_rd, bases, off + m - 1);
+    OutAcc18 acc;
+    SlidingWindow win;
+    win.init(off + m - 1);
 
-    auto emit = [&](uint64_t g, uint32_t len, uint32_t col_id, bool last) {   // :525
+    auto emit = [&](uint64_t g, uint32_t len, uint32_t col_id) {   // :525
         if constexpr (kWide) {
             pml[g] = (PmlT)len;
             cid[g] = (uint8_t)col_id;
         } else {
             acc.push(len, col_id);
-            if ((g & (kFlush - 1)) == 0 || last) acc.flush(pml, cid, g);
         }
     };
 
-    for (uint64_t k = m; k > 0;) {
-        uint64_t g = off + k - 1;
-        const uint32_t c = win.get(s_rd, g);             // :512 pattern[m-i-1], raw byte
-        const uint32_t col_id = sk_cid<K>(w);            // :513 before any re-orientation
-        if (sk_char<K>(w) == c) {                        // :516
-            ++L;
-        } else {
-            L = 0;                                       // :521
-            sk_threshold_step<K>(T, s_cmap, i, o, w, c); // :522
+    // col_bwt.hpp:503-508: pos = n-1 = the last position of the last row.  Expressed as an LF
+    // arrival at the last row with an offset beyond it, which the arrival clamps to len - 1.
+    uint32_t j = T.r - 1;
+    uint32_t o = kOffLastPos;
+    uint32_t L = 0;
+    uint64_t k = m;                                          // bases not yet reported
+    for (;;) {
+        uint64_t g = off + k - 1;                            // :512 pattern[m-i-1] is the next base
+        // the trip's memory traffic besides the row, issued while the wave is converged
+        if constexpr (!kWide) acc.flush_group((uint16_t *)pml, cid, g + 1);
+        {
+            const uint32_t want = k < (uint32_t)K ? (uint32_t)k : (uint32_t)K;   // bases a trip may consume
+            if (__any(win.avail(g) < want)) win.refill(s_rd, bases, g);
         }
-        --k;
-        emit(g, L, col_id, k == 0);
-        if (k == 0) break;                               // the last LF (:527) has no observable effect
-        if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
+        SKRow<K> w = sk_load<K>(T, j);
+        bool jump = true;                                    // false: j already names the next row to load
+        if (o != kOffPred && o != kOffSucc) {
+            const uint32_t len = sk_len<K>(w);
+            if (o >= len && j < T.r - 1) {
+                // fast-forward of LF_table::LF (LF_table.hpp:256-259) over level-K rows, two rows
+                // per trip (a row carries the next row's length)
+                o -= len;
+                uint32_t hop = 1;
+                const uint32_t l1 = sk_len8_next1<K>(w);
+                if (l1 != kLen8Long && o >= l1 && j + 1 < T.r - 1) {
+                    o -= l1;
+                    hop = 2;
+                }
+                j += hop;
+                jump = false;
+            } else {
+                o = o < len ? o : len - 1;
+                const uint32_t c = win.get(s_rd, g);         // raw byte
+                const uint32_t col_id = sk_cid<K>(w);        // :513 before any re-orientation
+                const bool match = sk_char<K>(w) == c;       // :516
+                L = match ? L + 1 : 0;                       // :517 / :521
+                --k;
+                emit(g, L, col_id);                  // :525
+                if (k == 0) break;                           // the last LF (:527) has no observable effect
+                --g;
+                if (!match) {                                // :522 threshold_step
+                    const uint32_t cidx = s_cmap[c];
+                    if (cidx != kAbsent) {                   // else (interval, offset) unchanged (:533-534)
+                        uint32_t hint = kHintCompare, dist = kSKDistFar;
+                        const uint32_t hs = hint_slot(cidx, s_cmap[sk_char<K>(w)]);
+                        if (hs < kHintSlots) {
+                            hint = (sk_hints<K>(w) >> (2 * hs)) & 3u;
+                            dist = sk_dist<K>(w, hs);
+                        }
+                        if (dist != kSKDistFar && hint != kHintCompare) {   // decided and close: the
+                            j = hint == kHintPred ? j - dist : j + dist;     // target is the next load
+                            o = hint == kHintPred ? kOffPred : kOffSucc;
+                            jump = false;
+                        } else {
+                            sk_threshold_scan<K>(T, j, o, w, c, cidx, hint);
+                        }
+                    }
+                }
+            }
+        } else {
+            o = o == kOffPred ? sk_len<K>(w) - 1 : 0;        // LF_table.hpp:282 / :296
+        }
+        if (!jump) continue;
 
         // After a-1 LF steps (:527) every position of this row is in one original row whose
         // character / col id are char_a / cid_a.  While the next base matches it, the next
@@ -134,39 +171,23 @@ void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_
         bool run = true;
         auto look = [&](uint32_t ch_a, uint32_t cid_a, uint32_t a) {
             if (!run) return;
-            if (win.get(s_rd, g - 1) != ch_a) { run = false; return; }
-            --g;
+            if (win.get(s_rd, g) != ch_a) { run = false; return; }
             ++L;
             --k;
-            emit(g, L, cid_a, k == 0);
+            emit(g, L, cid_a);
             steps = a;
             if (k == 0) { run = false; return; }
-            if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
+            --g;
         };
         look(sk_char_at<K, 2>(w), sk_cid_at<K, 2>(w), 2);
         if constexpr (K >= 3) look(sk_char_at<K, 3>(w), sk_cid_at<K, 3>(w), 3);
         if (k == 0) break;
-
-        // LF^steps, then the fast-forward of LF_table::LF (LF_table.hpp:256-259) over level-K
-        // rows, two rows per memory round trip (a row carries the next row's length)
-        uint32_t j = sk_I<K>(w, steps);
-        uint32_t t = sk_O<K>(w, steps) + o;
-        w = sk_load<K>(T, j);
-        for (;;) {
-            const uint32_t len = sk_len<K>(w);
-            if (t < len || j >= T.r - 1) break;
-            t -= len;
-            uint32_t hop = 1;
-            const uint32_t l1 = sk_len8_next1<K>(w);
-            if (l1 != kLen8Long && t >= l1 && j + 1 < T.r - 1) {
-                t -= l1;
-                hop = 2;
-            }
-            j += hop;
-            w = sk_load<K>(T, j);
-        }
-        i = j;
-        o = t;
+        o += sk_O<K>(w, steps);                              // LF^steps lands at (I_s, O_s + o)
+        j = sk_I<K>(w, steps);
+    }
+    if constexpr (!kWide) {                                  // k == 0: what the last trip pushed
+        acc.flush_group((uint16_t *)pml, cid, off);
+        acc.flush_rest((uint16_t *)pml, cid, off);
     }
 }
 

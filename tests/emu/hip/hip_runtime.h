@@ -86,6 +86,7 @@ static inline void __syncthreads() { emu::ctx.block->arrive(0); }
 static inline unsigned long long __ballot(int pred) {
     return emu::ctx.wave->arrive(pred ? (1ull << (emu::ctx.tid.x & 63)) : 0ull);
 }
+static inline int __any(int pred) { return __ballot(pred) != 0; }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o | v; return o;
 }
