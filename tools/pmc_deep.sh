@@ -7,14 +7,17 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 pass() {
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o b -- python3 "$REPO/bench.py" --no-cpu --steps 1 --warmup 0 > "$OUT/$name.json" 2> "$OUT/$name.err" || return 1
+  timeout -k 5 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o b -- python3 "$REPO/bench.py" --no-cpu --steps 1 --warmup 0 > "$OUT/$name.json" 2> "$OUT/$name.err" || return 1
 }
-pass p1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM SQ_INST_CYCLES_SALU &&
-pass p2 SQ_INSTS_BRANCH SQ_IFETCH SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM &&
-pass p3 GRBM_GUI_ACTIVE GRBM_TA_BUSY GRBM_UTCL2_BUSY TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum &&
+# SQ passes first; the TCP / TCC passes run under their own short timeout (a GRBM_* + TA_* pass
+# aborted inside rocprofv3 on this pool and then sat until the silence watchdog fired).
+pass p1 SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS &&
+pass p2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_BUSY_CYCLES SQ_INST_LEVEL_VMEM
+if [ -n "$DEEP_TCP" ]; then
 pass p4 TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum &&
 pass p5 TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum &&
 pass p6 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_BUSY_avr TCC_TAG_STALL_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
+fi
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, os, json
 out = sys.argv[1]; res = {}
