@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GATHER_CEILING_G = 41.0        # G random 128-byte line fills/s this chip sustains (tools/gather_littles.sh, 16-64 GiB tables)
 ALG_BYTES_PER_BASE = 27
 
 
@@ -142,10 +143,19 @@ def main():
         value = world * n_bases * args.steps / elapsed
         achieved = ALG_BYTES_PER_BASE * bases_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
+        line_fills = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         is_baseline_cfg = (args.rows, args.reads, args.read_len) == (200_000_000, 10_000_000, 150)
         if is_baseline_cfg and n_chunks == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            if info.layout == 3 and tj.get("read_requests_per_launch"):
+                # What actually bounds the kernel: the chip's rate of random
+                # 128-byte line fills, measured by tools/gather_littles.sh for this access shape.
+                req = tj["read_requests_per_launch"] + tj["write_requests_per_launch"]
+                line_fills = {"requests_per_launch": req, "achieved_G_per_s": req / (avg_launch_ms * 1e-3) / 1e9,
+                              "ceiling_G_per_s": GATHER_CEILING_G, "frac": req / (avg_launch_ms * 1e-3) / 1e9 / GATHER_CEILING_G,
+                              "ceiling_source": "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B loads per line)"}
         out = {
             "metric": "query bases/s", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -167,7 +177,7 @@ def main():
                          "kernel": (f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>"),
                          "avg_launch_ms": avg_launch_ms,
                          "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
-                         "bases_per_launch": bases_per_launch},
+                         "bases_per_launch": bases_per_launch, "line_fills": line_fills},
         }
 
     # ---- CPU baseline: the oracle (a port, the reference itself cannot travel) on a

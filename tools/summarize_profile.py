@@ -66,7 +66,9 @@ def main():
     if q and "hbm_bytes_per_launch" in q[0] and len(sys.argv) > 2 and sys.argv[2] == "--set-traffic":
         json.dump({"tag": tag, "hbm_bytes_per_launch": q[0]["hbm_bytes_per_launch"],
                    "hbm_read_bytes_per_launch": q[0]["hbm_read_bytes_per_launch"],
-                   "hbm_write_bytes_per_launch": q[0]["hbm_write_bytes_per_launch"]},
+                   "hbm_write_bytes_per_launch": q[0]["hbm_write_bytes_per_launch"],
+                   "read_requests_per_launch": q[0]["pmc_per_launch"].get("TCC_EA0_RDREQ_sum"),
+                   "write_requests_per_launch": q[0]["pmc_per_launch"].get("TCC_EA0_WRREQ_sum")},
                   open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(summary["kernels"], indent=1)[:3000])
 
