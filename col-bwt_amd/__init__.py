@@ -23,7 +23,7 @@ EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
     "colbwt_index_open_layout", "colbwt_index_open_memory_layout",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
-    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index",
+    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
 )
 
@@ -86,6 +86,7 @@ def lib():
     L.colbwt_synth_index_bytes.argtypes = [u64]
     L.colbwt_synth_index_bytes.restype = u64
     L.colbwt_synth_index.argtypes = [u64, C.c_uint32, C.c_uint32, u64, vp, u64]
+    L.colbwt_synth_index_thr.argtypes = [u64, C.c_uint32, C.c_uint32, u64, C.c_int, vp, u64]
     L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.colbwt_build_col_pml.argtypes = [C.c_char_p, C.c_char_p]
     L.colbwt_build_col_pml_arrays.argtypes = [vp, u64, vp, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(u64)]
@@ -190,11 +191,12 @@ class ColPml:
             pass
 
 
-def synth_index(rows, mean_len=8, split_permille=0, seed=42):
-    """Synthetic `.col_pml` image (SURVEY.md 8(d) recipe) as a uint8 numpy array."""
+def synth_index(rows, mean_len=8, split_permille=0, seed=42, thr_mode=0):
+    """Synthetic `.col_pml` image (SURVEY.md 8(d) recipe) as a uint8 numpy array.
+    thr_mode 0: thresholds uniform in [0, n); 1: between consecutive runs of a character."""
     nbytes = lib().colbwt_synth_index_bytes(rows)
     out = np.empty(nbytes, np.uint8)
-    _check(lib().colbwt_synth_index(rows, mean_len, split_permille, seed, out.ctypes.data, nbytes))
+    _check(lib().colbwt_synth_index_thr(rows, mean_len, split_permille, seed, thr_mode, out.ctypes.data, nbytes))
     return out
 
 

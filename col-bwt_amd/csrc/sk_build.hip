@@ -29,7 +29,33 @@ namespace {
 // ---- source views: what a refinement pass needs from the level below ------
 struct SrcL1 {  // the one-step table
     DevTable T;
+    HintChars chars;
     static constexpr int kSteps = 1;
+    // Positions strictly inside row i where a mismatch on one of the hinted characters
+    // changes sides: the threshold of that character's next run (col_bwt.hpp:552-560).
+    // The first refinement cuts there too, so that no refined row contains a threshold
+    // and every hint is decided -- in a real index the threshold of a run lies between
+    // the previous run of its character and its head, i.e. inside one of the rows in
+    // between, and the query would otherwise fall back to scans + position compares.
+    __device__ __forceinline__ uint32_t cuts(uint32_t i, uint64_t (&cut)[kHintSlots]) const {
+        const uint4 w = T.rows[i];
+        const uint32_t aidx = T.cmap[row_char(w)];
+        const uint32_t top = T.sigma < kHintMaxSigma ? T.sigma : kHintMaxSigma;
+        uint32_t nc = 0;
+        for (uint32_t cidx = 0; cidx < top; ++cidx) {
+            const uint32_t slot = hint_slot(cidx, aidx);
+            if (cidx == aidx || slot >= kHintSlots) continue;
+            if (((row_hints(w) >> (2 * slot)) & 3u) != kHintCompare) continue;
+            uint4 t;
+            const uint32_t s = succ_char(T, i, chars.c[cidx], cidx, t);
+            if (s == kNone) continue;                  // thr = n: never inside a row
+            const uint64_t thr = T.thr[s];
+            uint32_t q = nc++;                         // insertion sort, ascending
+            while (q > 0 && cut[q - 1] > thr) { cut[q] = cut[q - 1]; --q; }
+            cut[q] = thr;
+        }
+        return nc;
+    }
     __device__ __forceinline__ uint32_t rows() const { return T.r; }
     __device__ __forceinline__ uint64_t n() const { return T.n; }
     __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
@@ -50,6 +76,7 @@ template <int KS>
 struct SrcSK {  // a K-step table as the source of the next level
     SKTable T;
     static constexpr int kSteps = KS;
+    __device__ __forceinline__ uint32_t cuts(uint32_t, uint64_t (&)[kHintSlots]) const { return 0; }   // cut at level 2 already
     __device__ __forceinline__ uint32_t rows() const { return T.r; }
     __device__ __forceinline__ uint64_t n() const { return T.n; }
     __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
@@ -91,6 +118,9 @@ template <class Src, typename F>
 __device__ __forceinline__ void for_each_piece(const Src &S, uint32_t i, F f) {
     uint64_t rem = S.len(i);
     uint64_t b = S.idx(i);
+    uint64_t cut[kHintSlots];
+    const uint32_t nc = S.cuts(i, cut);
+    uint32_t ci = 0;
     uint32_t j;
     uint64_t t;
     S.lf(i, 1, j, t);
@@ -99,6 +129,8 @@ __device__ __forceinline__ void for_each_piece(const Src &S, uint32_t i, F f) {
     while (rem > 0) {
         const uint64_t avail = (j < S.rows() - 1 && t < lenj) ? lenj - t : rem;  // the last row absorbs everything
         uint64_t take = avail < rem ? avail : rem;
+        while (ci < nc && cut[ci] <= b) ++ci;                                   // thresholds inside the row
+        if (ci < nc && cut[ci] - b < take) take = cut[ci] - b;
         rem -= take;
         while (take > 0) {               // cut pieces longer than kSKMaxLen
             const uint64_t piece = take < kSKMaxLen ? take : kSKMaxLen;
@@ -107,7 +139,7 @@ __device__ __forceinline__ void for_each_piece(const Src &S, uint32_t i, F f) {
             t += piece;
             take -= piece;
         }
-        if (rem > 0) {
+        if (rem > 0 && t >= lenj && j < S.rows() - 1) {
             ++j;
             t = 0;
             lenj = S.len(j);
@@ -447,7 +479,7 @@ void SKBuffers::release() {
 // Builds the `steps`-step layout (2 or 3) from the one-step tables of `T`.  Returns false
 // with `err` set when it cannot (more than 2^32-2 rows, out of memory).
 bool build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err) {
-    SrcL1 s1{T};
+    SrcL1 s1{T, chars};
     if (steps == 2) return build_level<SrcL1, 2>(s1, T.r, T.cmap, T.sigma, chars, true, out, buf, err);
     // level 3 is refined from a temporary level 2
     SKTable t2{};

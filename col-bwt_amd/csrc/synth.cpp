@@ -33,7 +33,13 @@ extern "C" uint64_t colbwt_synth_index_bytes(uint64_t rows) {
 
 extern "C" int colbwt_synth_index(uint64_t rows, uint32_t mean_len, uint32_t split_permille, uint64_t seed, void *out,
                                   uint64_t out_len) {
+    return colbwt_synth_index_thr(rows, mean_len, split_permille, seed, COLBWT_SYNTH_THR_UNIFORM, out, out_len);
+}
+
+extern "C" int colbwt_synth_index_thr(uint64_t rows, uint32_t mean_len, uint32_t split_permille, uint64_t seed,
+                                      int thr_mode, void *out, uint64_t out_len) {
     using namespace colbwt;
+    if (thr_mode != COLBWT_SYNTH_THR_UNIFORM && thr_mode != COLBWT_SYNTH_THR_BETWEEN_RUNS) return COLBWT_ERR_ARG;
     if (!out || rows < 2 || rows > 0xFFFFFFFEull || mean_len < 1 || mean_len > 60000 || split_permille >= 1000 ||
         out_len < colbwt_synth_index_bytes(rows))
         return COLBWT_ERR_ARG;
@@ -83,14 +89,39 @@ extern "C" int colbwt_synth_index(uint64_t rows, uint32_t mean_len, uint32_t spl
     }
     if (n >= (1ull << 40)) return COLBWT_ERR_ARG;
 
-    // pass 2: thresholds uniform in [0, n); sub-runs of one BWT run share a threshold
-    // (col_pml::read_thresholds copies a run's threshold to all its sub-runs, col_bwt.hpp:448-454)
+    // pass 2: thresholds; sub-runs of one BWT run share a threshold (col_pml::read_thresholds
+    // copies a run's threshold to all its sub-runs, col_bwt.hpp:448-454).
+    //   UNIFORM       uniform in [0, n) (the SURVEY.md 8(d) recipe)
+    //   BETWEEN_RUNS  where real thresholds live: a position between the end of the previous run
+    //                 of the same character and the head of this run; 0 for a character's first run
     {
         uint64_t thr = 0;
+        uint64_t last_end[256];
+        bool seen[256];
+        memset(last_end, 0, sizeof(last_end));
+        memset(seen, 0, sizeof(seen));
+        auto idx_at = [&](uint64_t i) -> uint64_t {
+            if (i >= r) return n;
+            const uint8_t *q = row + i * kRowBytesDisk + 1;
+            uint64_t v = 0;
+            for (int b = 0; b < 5; ++b) v |= (uint64_t)q[b] << (8 * b);
+            return v;
+        };
         for (uint64_t i = 0; i < r; ++i) {
             uint8_t *p = row + i * kRowBytesDisk;
-            if (i == 0 || p[0] != (p - kRowBytesDisk)[0]) thr = splitmix64(seed ^ 0xABCDull ^ (i * 0xD6E8FEB86659FD93ull)) % n;
+            const uint8_t c = p[0];
+            if (i == 0 || c != (p - kRowBytesDisk)[0]) {      // head of a BWT run
+                const uint64_t h = splitmix64(seed ^ 0xABCDull ^ (i * 0xD6E8FEB86659FD93ull));
+                if (thr_mode == COLBWT_SYNTH_THR_UNIFORM) {
+                    thr = h % n;
+                } else {
+                    const uint64_t head = idx_at(i);
+                    thr = seen[c] ? last_end[c] + h % (head - last_end[c] + 1) : 0;
+                }
+            }
             put_le(p + 13, thr, 5);
+            seen[c] = true;
+            last_end[c] = idx_at(i + 1);                      // one past the run's last position
         }
     }
 

@@ -175,6 +175,13 @@ uint64_t colbwt_synth_index_bytes(uint64_t rows);
  * Writes the file image into `out` (colbwt_synth_index_bytes(rows) bytes). */
 int colbwt_synth_index(uint64_t rows, uint32_t mean_len, uint32_t split_permille, uint64_t seed,
                        void *out, uint64_t out_len);
+/* As above with a choice of where the thresholds fall: UNIFORM in [0, n) (the
+ * SURVEY.md 8(d) recipe), or BETWEEN_RUNS: between the previous run of the same
+ * character and the run's head, as in a real index (mumemto's .thr_pos). */
+#define COLBWT_SYNTH_THR_UNIFORM 0
+#define COLBWT_SYNTH_THR_BETWEEN_RUNS 1
+int colbwt_synth_index_thr(uint64_t rows, uint32_t mean_len, uint32_t split_permille, uint64_t seed,
+                           int thr_mode, void *out, uint64_t out_len);
 /* Backward-walk reads sampled ON THE DEVICE from the loaded index:
  * read[m-1-k] = char at LF^k(p0), p0 uniform; 0x01 -> 'A'; substitutions at
  * `sub_permille`/1000.  Writes n_reads*read_len bytes (+64 pad bytes zeroed)

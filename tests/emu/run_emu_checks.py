@@ -90,6 +90,8 @@ def main():
         reads += rand_reads(rng, 40, 0, 90)
         reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
         check(img, reads, f"synth_{rows}_{split}")
+    img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=8, thr_mode=1)   # thresholds inside rows: cut out
+    check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs")
 
     # 4. rare character far away: scans must leave the block and use the jump tables
     r = 2000

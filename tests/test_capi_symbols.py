@@ -48,3 +48,28 @@ def test_synth_index_is_a_consistent_move_table(pkg):
         same = ~heads[1:]
         assert np.all(t["thr"][1:][same] == t["thr"][:-1][same])
         assert (t["char"] == 1).sum() == 1
+
+
+def test_synth_index_thresholds_between_runs(pkg):
+    """thr_mode 1: the threshold of a BWT run lies between the end of the previous run of
+    the same character and the run's head (0 for a character's first run); everything else
+    is the same table as thr_mode 0."""
+    import helpers
+    img0 = helpers.unpack_col_pml(pkg.synth_index(4000, mean_len=6, split_permille=100, seed=5).tobytes())
+    t = helpers.unpack_col_pml(pkg.synth_index(4000, mean_len=6, split_permille=100, seed=5, thr_mode=1).tobytes())
+    for k in ("char", "idx", "interval", "offset", "cid"):
+        assert np.array_equal(img0[k], t[k])
+    idx = t["idx"].astype(np.int64)
+    end = np.append(idx[1:], t["n"])
+    last_end = {}
+    for i in range(int(t["r"])):
+        c = int(t["char"][i])
+        if i == 0 or t["char"][i - 1] != c:
+            lo = last_end.get(c)
+            if lo is None:
+                assert t["thr"][i] == 0
+            else:
+                assert lo <= int(t["thr"][i]) <= idx[i]
+            head_thr = t["thr"][i]
+        assert t["thr"][i] == head_thr
+        last_end[c] = int(end[i])

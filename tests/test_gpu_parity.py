@@ -98,6 +98,20 @@ def test_synthetic_tables(pkg, oracle, rows, split, seed):
     _check(pkg, oracle, image, reads)
 
 
+def test_thresholds_between_runs_are_cut_out_of_refined_rows(pkg, oracle):
+    """Realistic thresholds (inside the rows between two runs of a character): the K-step
+    build cuts rows there; results must not change, the refined tables get the extra rows."""
+    rng = np.random.default_rng(8)
+    image = pkg.synth_index(60_000, mean_len=6, split_permille=50, seed=8, thr_mode=1)
+    uniform = pkg.synth_index(60_000, mean_len=6, split_permille=50, seed=8, thr_mode=0)
+    reads = helpers.backward_walk_reads(image.tobytes(), 1500, 150, 0.03, seed=8) + _rand_reads(rng, 500, 0, 200)
+    _check(pkg, oracle, image, reads)
+    a = pkg.ColPml.from_bytes(image.tobytes(), layout=3)
+    b = pkg.ColPml.from_bytes(uniform.tobytes(), layout=3)
+    assert a.info().table_rows > b.info().table_rows
+    a.close(), b.close()
+
+
 def test_rare_character_uses_jump_tables(pkg, oracle):
     rng = np.random.default_rng(31)
     r = 20_000

@@ -44,12 +44,13 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-permille", type=int, default=10)
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--thr-mode", type=int, default=0, help="0: thresholds uniform in [0,n) (C2 recipe); 1: between runs")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import torch
     pkg = load_package()
     dev = torch.device("cuda", 0)
-    image = pkg.synth_index(a.rows, 8, 0, 42)
+    image = pkg.synth_index(a.rows, 8, 0, 42, a.thr_mode)
     n_reads, m = a.reads, a.read_len
     nb = n_reads * m
     d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
