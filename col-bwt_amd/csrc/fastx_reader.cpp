@@ -3,18 +3,32 @@
 #include "fastx_reader.h"
 
 #include <ctype.h>
+#include <fcntl.h>
+#include <string.h>
+#include <unistd.h>
 
 namespace colbwt {
 
 FastxReader::~FastxReader() {
     if (fp_) gzclose(fp_);
+    if (raw_fd_ >= 0) ::close(raw_fd_);
 }
 
 bool FastxReader::open(const std::string &path) {
-    fp_ = gzopen(path.c_str(), "r");  // io.hpp:9 (gzopen reads plain files transparently)
-    if (!fp_) return false;
-    gzbuffer(fp_, 1 << 20);
-    buf_.resize(1 << 20);
+    // io.hpp:9 gzopen reads plain files transparently; a regular file that does not start with
+    // the gzip magic is read with read(2) directly -- the same bytes
+    raw_fd_ = ::open(path.c_str(), O_RDONLY);
+    if (raw_fd_ < 0) return false;
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = ::pread(raw_fd_, magic, 2, 0);
+    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        ::close(raw_fd_);
+        raw_fd_ = -1;
+        fp_ = gzopen(path.c_str(), "r");
+        if (!fp_) return false;
+        gzbuffer(fp_, 1 << 20);
+    }
+    buf_.resize(4 << 20);
     begin_ = end_ = 0;
     eof_ = false;
     pending_header_ = 0;
@@ -24,7 +38,8 @@ bool FastxReader::open(const std::string &path) {
 int FastxReader::getc_() {
     if (begin_ >= end_) {
         if (eof_) return -1;
-        const int got = gzread(fp_, buf_.data(), (unsigned)buf_.size());
+        const int got = fp_ ? gzread(fp_, buf_.data(), (unsigned)buf_.size())
+                            : (int)::read(raw_fd_, buf_.data(), buf_.size());
         if (got <= 0) {
             eof_ = true;
             return -1;
@@ -44,8 +59,8 @@ bool FastxReader::rest_of_line_(std::vector<uint8_t> *dst, size_t base_len) {
             --begin_;  // put it back; the scan below consumes it
         }
         any = true;
-        size_t i = begin_;
-        while (i < end_ && buf_[i] != '\n') ++i;
+        const void *nl = memchr(buf_.data() + begin_, '\n', end_ - begin_);
+        const size_t i = nl ? (size_t)((const uint8_t *)nl - buf_.data()) : end_;
         if (dst) dst->insert(dst->end(), buf_.begin() + begin_, buf_.begin() + i);
         const bool hit = i < end_;
         begin_ = hit ? i + 1 : i;
@@ -58,7 +73,7 @@ bool FastxReader::rest_of_line_(std::vector<uint8_t> *dst, size_t base_len) {
 }
 
 bool FastxReader::next(std::string &name, std::vector<uint8_t> &bases) {
-    if (!fp_) return false;
+    if (!fp_ && raw_fd_ < 0) return false;
     int c;
     if (!pending_header_) {
         while ((c = getc_()) >= 0 && c != '>' && c != '@') {}

@@ -37,6 +37,8 @@ private:
     bool rest_of_line_(std::vector<uint8_t> *dst, size_t base_len);
 
     gzFile fp_ = nullptr;
+    int raw_fd_ = -1;   // a file without the gzip magic is read directly (what zlib's transparent
+                        // mode would hand back, without its extra copy)
     std::vector<uint8_t> buf_;
     size_t begin_ = 0, end_ = 0;
     bool eof_ = false;

@@ -5,6 +5,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -32,10 +33,19 @@ public:
 
 private:
     bool flush_();
-    FILE *f_ = nullptr;
+    bool write_all_(const char *p, size_t n);
+    int fd_ = -1;
+    uint64_t pos_ = 0;                 // file offset of the next byte
     std::vector<char> buf_;
     size_t used_ = 0;
     bool ok_ = true;
+    // formatting buffers of batch(), one per worker, kept across calls (fresh pages cost as
+    // much as the formatting itself)
+    struct Chunk {
+        char *p = nullptr;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Chunk> chunks_;
 };
 
 }  // namespace colbwt

@@ -69,6 +69,24 @@ def main():
     tbl.close()
     print("ok kat_d text")
 
+    # 1b. the pipelined file path: several batches, multi-threaded formatting (> 1 MiB of
+    #     values per batch), values of five digits
+    img = pkg.synth_index(3000, mean_len=6, split_permille=50, seed=21)
+    reads = helpers.backward_walk_reads(img, 1500, 750, 0.002, seed=21)
+    reads += helpers.backward_walk_reads(img, 1, 11000, 0.0, seed=22) + rand_reads(rng, 200, 0, 300)
+    with tempfile.TemporaryDirectory() as d:
+        fa = os.path.join(d, "big.fa")
+        helpers.write_fasta(fa, reads, width=80)
+        tbl = pkg.ColPml.from_bytes(img)
+        st = tbl.query_file(fa, batch_bases=450_000)
+        assert st.n_reads == len(reads)
+        oracle.OracleIndex(bytes(img)).pml_query_files(fa, fa + ".opml", fa + ".ocid")
+        for ext in ("pml", "cid"):
+            assert open(fa + "." + ext, "rb").read() == open(fa + ".o" + ext, "rb").read(), ext
+        assert b" 10000 " in open(fa + ".pml", "rb").read()
+        tbl.close()
+    print("ok big text")
+
     # 2. true BWT index, reads with substitutions, N and lowercase (no case folding)
     seqs = []
     base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300)
