@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="pipeline chunks per step (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", choices=("packed", "raw"), default="packed",
+                    help="N > 1: PML values travel to rank 0 as one bit per base (gather codec) or as u16")
     return ap.parse_args()
 
 
@@ -96,8 +98,32 @@ def main():
     n_chunks = args.chunks or (1 if world == 1 else 4)
     pml_bytes = d_pml.view(torch.uint8)[:2 * n_bases]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
-                                    [(pml_bytes, 2), (d_cid[:n_bases], 1)], dev, (stream, comm_stream))
+    codec = None
+    g_pml = None                                   # rank 0, packed gather: the rebuilt (world, bases) u16 values
+    if world > 1 and args.gather == "packed":
+        words = (n_bases + 31) // 32
+        d_zero = torch.zeros(words, dtype=torch.int32, device=dev)
+        g_zero = torch.zeros((world, 4 * words), dtype=torch.uint8, device=dev) if rank == 0 else None
+        if rank == 0:
+            d_end = torch.zeros(words, dtype=torch.int32, device=dev)       # same read lengths on every rank
+            pkg.read_end_mask_device(d_off.data_ptr(), n_reads, d_end.data_ptr(), stream.cuda_stream)
+            g_pml = torch.zeros((world, words * 32), dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
+
+        def pack(lo_base, nb):
+            pkg.pml_pack_device(d_pml.data_ptr() + 2 * lo_base, nb, d_zero.data_ptr() + 4 * (lo_base // 32),
+                                stream.cuda_stream)
+
+        def unpack(r, w0, nw):
+            pkg.pml_unpack_device(g_zero[r].data_ptr(), d_end.data_ptr(), w0, nw, words, g_pml[r].data_ptr(),
+                                  comm_stream.cuda_stream)
+
+        codec = multi_gpu.PmlCodec(d_zero.view(torch.uint8), pack, unpack, g_zero)
+        outputs = [(d_cid[:n_bases], 1)]
+    else:
+        outputs = [(pml_bytes, 2), (d_cid[:n_bases], 1)]
+    pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, outputs, dev, (stream, comm_stream),
+                                    pml_codec=codec)
     kernel_events = []
 
     def query_chunk(lo, hi):
@@ -133,6 +159,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # N > 1 (untimed): the gathered results against a plain u16 gather of the same outputs
+    gather_ok = None
+    if world > 1:
+        raw = [torch.empty(n_bases, dtype=torch.int16, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(d_pml[:n_bases].contiguous(), raw, dst=0)
+        rawc = [torch.empty(n_bases, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        dist.gather(d_cid[:n_bases].contiguous(), rawc, dst=0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            got_c = pipe.gathered[-1]
+            gather_ok = all(bool(torch.equal(got_c[r], rawc[r])) for r in range(world))
+            if codec:
+                gather_ok = gather_ok and all(bool(torch.equal(g_pml[r][:n_bases], raw[r])) for r in range(world))
+            else:
+                gp = pipe.gathered[0].view(torch.int16)
+                gather_ok = gather_ok and all(bool(torch.equal(gp[r], raw[r])) for r in range(world))
+            del raw, rawc
+
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
     launches = len(kernel_ms)
     avg_launch_ms = sum(kernel_ms) / max(launches, 1)
@@ -165,8 +209,10 @@ def main():
                                    f"backward-walk reads per GPU, {args.sub_permille / 10:.1f}% substitutions"
                                    + ("" if is_baseline_cfg else " [REDUCED rehearsal size]"),
                        "rows": int(info.r), "reads_per_gpu": n_reads, "read_len": m,
-                       "parallelism": f"reads sharded x{world}, index replicated, RCCL gather to rank 0"
+                       "parallelism": (f"reads sharded x{world}, index replicated, RCCL gather to rank 0 "
+                                       + ("(PML as 1 bit/base + col ids: 1.125 B/base)" if codec else "(3 B/base)"))
                        if world > 1 else "single GPU",
+                       "gather_matches_plain_gather": gather_ok,
                        "pipeline_chunks": n_chunks,
                        "index_gen_s": round(t_gen, 2), "index_load_s": round(t_load, 2),
                        "index_hbm_bytes": int(info.device_bytes),

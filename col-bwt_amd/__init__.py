@@ -23,7 +23,7 @@ EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
     "colbwt_index_open_layout", "colbwt_index_open_memory_layout",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
-    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr",
+    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
 )
 
@@ -87,6 +87,9 @@ def lib():
     L.colbwt_synth_index_bytes.restype = u64
     L.colbwt_synth_index.argtypes = [u64, C.c_uint32, C.c_uint32, u64, vp, u64]
     L.colbwt_synth_index_thr.argtypes = [u64, C.c_uint32, C.c_uint32, u64, C.c_int, vp, u64]
+    L.colbwt_pml_pack_device.argtypes = [vp, u64, vp, vp]
+    L.colbwt_read_end_mask_device.argtypes = [vp, u64, vp, vp]
+    L.colbwt_pml_unpack_device.argtypes = [vp, vp, u64, u64, u64, vp, vp]
     L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.colbwt_build_col_pml.argtypes = [C.c_char_p, C.c_char_p]
     L.colbwt_build_col_pml_arrays.argtypes = [vp, u64, vp, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(u64)]
@@ -189,6 +192,21 @@ class ColPml:
             self.close()
         except Exception:
             pass
+
+
+def pml_pack_device(d_pml, n_bases, d_mask, stream=0):
+    """Gather codec (include/colbwt.h): one bit per base, set where the PML value is 0."""
+    _check(lib().colbwt_pml_pack_device(d_pml, n_bases, d_mask, stream))
+
+
+def read_end_mask_device(d_read_off, n_reads, d_mask, stream=0):
+    """Bit set at the last base of every non-empty read (d_mask zeroed by the caller)."""
+    _check(lib().colbwt_read_end_mask_device(d_read_off, n_reads, d_mask, stream))
+
+
+def pml_unpack_device(d_zero_mask, d_end_mask, first_word, n_words, total_words, d_pml, stream=0):
+    """Rebuilds the u16 PML values of 32-base words [first_word, first_word + n_words)."""
+    _check(lib().colbwt_pml_unpack_device(d_zero_mask, d_end_mask, first_word, n_words, total_words, d_pml, stream))
 
 
 def synth_index(rows, mean_len=8, split_permille=0, seed=42, thr_mode=0):

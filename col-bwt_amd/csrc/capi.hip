@@ -508,6 +508,40 @@ int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *p
     return COLBWT_OK;
 }
 
+int colbwt_pml_pack_device(const uint16_t *d_pml, uint64_t n_bases, uint32_t *d_mask, void *hip_stream) {
+    if (!d_pml || !d_mask) return fail(COLBWT_ERR_ARG, "null argument");
+    if ((uintptr_t)d_pml % 32 || (uintptr_t)d_mask % 4) return fail(COLBWT_ERR_ARG, "d_pml must be 32-byte aligned");
+    launch_pml_pack(d_pml, n_bases, d_mask, (hipStream_t)hip_stream);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(COLBWT_ERR_HIP, std::string("colbwt_pml_pack_device: ") + hipGetErrorString(e));
+    }
+    return COLBWT_OK;
+}
+
+int colbwt_read_end_mask_device(const uint64_t *d_read_off, uint64_t n_reads, uint32_t *d_mask, void *hip_stream) {
+    if (!d_read_off || !d_mask) return fail(COLBWT_ERR_ARG, "null argument");
+    launch_read_end_mask(d_read_off, n_reads, d_mask, (hipStream_t)hip_stream);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(COLBWT_ERR_HIP, std::string("colbwt_read_end_mask_device: ") + hipGetErrorString(e));
+    }
+    return COLBWT_OK;
+}
+
+int colbwt_pml_unpack_device(const uint32_t *d_zero_mask, const uint32_t *d_end_mask, uint64_t first_word,
+                             uint64_t n_words, uint64_t total_words, uint16_t *d_pml, void *hip_stream) {
+    if (!d_zero_mask || !d_end_mask || !d_pml) return fail(COLBWT_ERR_ARG, "null argument");
+    if (first_word + n_words > total_words) return fail(COLBWT_ERR_ARG, "word range beyond the masks");
+    if ((uintptr_t)d_pml % 64) return fail(COLBWT_ERR_ARG, "d_pml must be 64-byte aligned");
+    launch_pml_unpack(d_zero_mask, d_end_mask, first_word, n_words, total_words, d_pml, (hipStream_t)hip_stream);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(COLBWT_ERR_HIP, std::string("colbwt_pml_unpack_device: ") + hipGetErrorString(e));
+    }
+    return COLBWT_OK;
+}
+
 int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                               uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, void *hip_stream) {
     if (!idx || !d_bases || !d_read_off || read_len == 0) return fail(COLBWT_ERR_ARG, "bad argument");

@@ -47,6 +47,12 @@ struct HintChars {
 };
 void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, hipStream_t stream);
 
+// gather_codec.hip: one bit per base for the PML values on their way to rank 0
+void launch_pml_pack(const uint16_t *d_pml, uint64_t n_bases, uint32_t *d_mask, hipStream_t stream);
+void launch_read_end_mask(const uint64_t *d_read_off, uint64_t n_reads, uint32_t *d_mask, hipStream_t stream);
+void launch_pml_unpack(const uint32_t *d_flag, const uint32_t *d_last, uint64_t first_word, uint64_t n_words,
+                       uint64_t total_words, uint16_t *d_pml, hipStream_t stream);
+
 // Device allocations of one K-step table.
 struct SKBuffers {
     void *lines = nullptr, *idx = nullptr, *thr = nullptr, *next = nullptr, *prev = nullptr;

@@ -6,7 +6,11 @@ contiguous read ranges balanced by base count, the index replicated in every
 GPU's HBM, no collective on the data path.  The only exchange is the gather of
 the per-base outputs to rank 0 (RCCL over xGMI: `torch.distributed` backend
 "nccl"), pipelined in chunks behind the compute so the links work while the
-next chunk is being queried.
+next chunk is being queried.  The 16-bit PML values travel as ONE BIT per base
+(`PmlCodec`; include/colbwt.h "multi-GPU gather codec"): a read's values are
+determined by where they are zero, so 3 bytes per base become 1.125 and rank 0
+rebuilds the values on its own GPU -- rank 0's ingest over its 7 xGMI links is
+what limits the job at N = 8, not the query.
 
 Everything here is backend-agnostic plumbing (also exercised with gloo on CPU
 tensors by tests/test_multi_gpu_gloo.py); the compute is injected as a callable.
@@ -28,10 +32,28 @@ def shard_reads(read_off, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def chunk_bounds(n_reads, n_chunks):
-    """Read-index boundaries of the pipeline chunks of one rank's shard."""
+def chunk_bounds(n_reads, n_chunks, align=1):
+    """Read-index boundaries of the pipeline chunks of one rank's shard; inner
+    boundaries are multiples of `align` reads."""
     n_chunks = max(1, min(n_chunks, max(n_reads, 1)))
-    return [n_reads * c // n_chunks for c in range(n_chunks + 1)]
+    b = [min(n_reads, (n_reads * c // n_chunks) // align * align) for c in range(n_chunks)] + [n_reads]
+    return [x for k, x in enumerate(b) if k == 0 or k == len(b) - 1 or x > b[k - 1]] if align > 1 else b
+
+
+class PmlCodec:
+    """One bit per base for the PML values on their way to rank 0 (fixed-length reads).
+
+    The three callables get plain integers (element / word indices) and run on the
+    caller's current stream: the HIP kernels of csrc/gather_codec.hip on a GPU
+    (bench.py), numpy stand-ins in the gloo test.
+      pack(lo_base, n_bases)              local values -> local zero mask
+      unpack(r, first_word, n_words)      rank 0: gathered zero mask of rank r -> its values
+    `mask` is the local zero mask as a uint8 tensor of whole 32-bit words; on rank 0
+    `gathered_mask` is (world, mask.numel()) and the rebuilt values live with the caller.
+    """
+
+    def __init__(self, mask, pack, unpack, gathered_mask=None):
+        self.mask, self.pack, self.unpack, self.gathered_mask = mask, pack, unpack, gathered_mask
 
 
 class GatherPipeline:
@@ -44,13 +66,16 @@ class GatherPipeline:
     On rank 0 `gathered[k]` is a (world, bytes) uint8 tensor per output.
     """
 
-    def __init__(self, dist, rank, world, n_reads, read_len, n_chunks, outputs, device, streams=None):
+    def __init__(self, dist, rank, world, n_reads, read_len, n_chunks, outputs, device, streams=None,
+                 pml_codec=None):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = rank, world
         self.m = read_len
-        self.bounds = chunk_bounds(n_reads, n_chunks)
+        # with the codec a chunk must start on a 32-base word: 32 reads of any length do
+        self.bounds = chunk_bounds(n_reads, n_chunks, 32 if pml_codec else 1)
         self.outputs = outputs
+        self.codec = pml_codec
         self.cuda = device.type == "cuda"
         self.compute_stream, self.comm_stream = streams if streams else (None, None)
         self.gathered = None
@@ -69,6 +94,8 @@ class GatherPipeline:
                 on_launch("after")
             if self.world == 1:
                 continue
+            if self.codec:
+                self.codec.pack(lo * self.m, (hi - lo) * self.m)
             if self.cuda:
                 done = torch.cuda.Event()
                 done.record(self.compute_stream)
@@ -82,6 +109,16 @@ class GatherPipeline:
                     a, b = bpb * lo * self.m, bpb * hi * self.m
                     glist = [self.gathered[k][r, a:b] for r in range(self.world)] if self.rank == 0 else None
                     works.append(dist.gather(src[a:b], glist, dst=0, async_op=True))
+                if self.codec:
+                    w0, w1 = lo * self.m // 32, (hi * self.m + 31) // 32      # whole words of the chunk
+                    gm = self.codec.gathered_mask
+                    glist = [gm[r, 4 * w0:4 * w1] for r in range(self.world)] if self.rank == 0 else None
+                    work = dist.gather(self.codec.mask[4 * w0:4 * w1], glist, dst=0, async_op=True)
+                    works.append(work)
+                    if self.rank == 0:
+                        work.wait()          # orders the comm stream behind the gather (blocks on gloo)
+                        for r in range(self.world):
+                            self.codec.unpack(r, w0, w1 - w0)
         for w in works:
             w.wait()
         if self.cuda and self.comm_stream is not None and self.world > 1:

@@ -163,6 +163,26 @@ int colbwt_build_col_pml_arrays(const uint8_t *heads, uint64_t n_heads, const ui
                                 uint64_t n_splits, const uint64_t *thr_pos, uint64_t n_thr, void *out,
                                 uint64_t out_cap, uint64_t *out_len);
 
+/* ---- multi-GPU gather codec (the path's one exchange step) -----------------
+ * The reference has no counterpart: its reads are processed by one process
+ * (pml_query.cpp:74).  With the reads sharded over N GPUs the per-base results
+ * are gathered on rank 0; the PML values of a read are determined by where
+ * they are zero (length + 1 per match, 0 at a mismatch: col_bwt.hpp:516-521),
+ * so a rank sends one bit per base and rank 0 rebuilds the 16-bit values.
+ * Device pointers; masks are uint32 words, bit b of word w = base 32w + b of
+ * the rank's concatenated reads; all calls are asynchronous on `hip_stream`.
+ *   pack     d_mask[(n_bases+31)/32] <- (d_pml[k] == 0); d_pml 32-byte aligned
+ *   end mask bit (read_off[r+1]-1) set for every non-empty read; d_mask must be
+ *            zeroed by the caller, (n_bases+31)/32 words
+ *   unpack   rebuilds d_pml[32*first_word .. 32*(first_word+n_words)) from the
+ *            zero mask and the end mask (both total_words long; the range must
+ *            end at a read end or at total_words); d_pml needs room for whole
+ *            32-value blocks and 64-byte alignment */
+int colbwt_pml_pack_device(const uint16_t *d_pml, uint64_t n_bases, uint32_t *d_mask, void *hip_stream);
+int colbwt_read_end_mask_device(const uint64_t *d_read_off, uint64_t n_reads, uint32_t *d_mask, void *hip_stream);
+int colbwt_pml_unpack_device(const uint32_t *d_zero_mask, const uint32_t *d_end_mask, uint64_t first_word,
+                             uint64_t n_words, uint64_t total_words, uint16_t *d_pml, void *hip_stream);
+
 /* ---- synthetic inputs (benchmark / test generators) ------ */
 
 /* Bytes needed for a synthetic .col_pml image of `rows` rows. */

@@ -87,6 +87,42 @@ def main():
         tbl.close()
     print("ok big text")
 
+    # 1c. gather codec (multi-GPU exchange step): PML values <-> one bit per base
+    def aligned(n, dt):
+        raw = np.zeros(n * np.dtype(dt).itemsize + 64, np.uint8)
+        o = (-raw.ctypes.data) % 64
+        return raw[o:o + n * np.dtype(dt).itemsize].view(dt)
+    creads = reads[:300] + [np.zeros(0, np.uint8)] * 3 + rand_reads(rng, 40, 1, 5)
+    cb, coff = helpers.concat_reads(creads)
+    epml, _ = oracle.OracleIndex(bytes(img)).query_batch(cb, coff)
+    nb = int(coff[-1])
+    nw = (nb + 31) // 32
+    d_pml = aligned(nw * 32, np.uint16)
+    d_pml[:nb] = epml
+    d_pml[nb:] = 7                                   # padding must not leak into the mask
+    zero, last = aligned(nw, np.uint32), aligned(nw, np.uint32)
+    d_off = aligned(len(coff), np.uint64)
+    d_off[:] = coff
+    pkg.pml_pack_device(d_pml.ctypes.data, nb, zero.ctypes.data)
+    pkg.read_end_mask_device(d_off.ctypes.data, len(creads), last.ctypes.data)
+    bits = np.unpackbits(zero.view(np.uint8), bitorder="little")[:nb]
+    assert np.array_equal(bits.astype(bool), epml == 0)
+    ends = np.unpackbits(last.view(np.uint8), bitorder="little")[:nb]
+    assert ends.sum() == sum(1 for r in creads if len(r)) and all(ends[int(e) - 1] for e in coff[1:] if e > 0)
+    out = aligned(nw * 32, np.uint16)
+    cutw = int(coff[150]) // 32                      # a word boundary inside a read: two calls
+    cut_read_end = None
+    for e in coff[100:]:
+        if int(e) % 32 == 0 and e > 0:
+            cut_read_end = int(e) // 32
+            break
+    first = cut_read_end if cut_read_end else 0      # chunked: [0, first) then [first, nw)
+    del cutw
+    pkg.pml_unpack_device(zero.ctypes.data, last.ctypes.data, 0, first, nw, out.ctypes.data)
+    pkg.pml_unpack_device(zero.ctypes.data, last.ctypes.data, first, nw - first, nw, out.ctypes.data)
+    assert np.array_equal(out[:nb], epml), np.flatnonzero(out[:nb] != epml)[:10]
+    print(f"ok gather codec: {len(creads)} reads, {nb} bases, split at word {first}")
+
     # 2. true BWT index, reads with substitutions, N and lowercase (no case folding)
     seqs = []
     base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300)

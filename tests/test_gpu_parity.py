@@ -379,3 +379,66 @@ def test_fuzz_random_tables_all_layouts(pkg, oracle, seed0):
         reads = _rand_reads(rng, 300, 0, 200, alphabet=alpha + b"\xfe")
         reads += helpers.backward_walk_reads(img, 300, int(rng.integers(1, 400)), 0.02, seed=seed)
         _check(pkg, oracle, img, reads)
+
+
+def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
+    """The multi-GPU exchange step on one GPU: PML values -> one bit per base -> values, through
+    the same GatherPipeline / PmlCodec wiring bench.py uses, with the collective replaced by a
+    device copy (every 'rank' contributes this GPU's results)."""
+    import torch
+    import __graft_entry__  # noqa: F401  (registers colbwt_amd)
+    from colbwt_amd import multi_gpu
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(100_000, mean_len=8, seed=3)
+    tbl = pkg.ColPml.from_bytes(image.tobytes())
+    n_reads, m, world = 20_011, 150, 3            # n_reads * m is not a multiple of 32
+    nb = n_reads * m
+    d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    tbl.synth_reads_device(n_reads, m, 20, 7, d_bases.data_ptr(), d_off.data_ptr())
+    d_pml = torch.zeros(nb + 16, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
+    stream, comm = torch.cuda.current_stream(), torch.cuda.Stream(device=dev)
+    words = (nb + 31) // 32
+    d_zero = torch.zeros(words, dtype=torch.int32, device=dev)
+    d_end = torch.zeros(words, dtype=torch.int32, device=dev)
+    g_zero = torch.zeros((world, 4 * words), dtype=torch.uint8, device=dev)
+    g_pml = torch.full((world, words * 32), -1, dtype=torch.int16, device=dev)
+    pkg.read_end_mask_device(d_off.data_ptr(), n_reads, d_end.data_ptr(), stream.cuda_stream)
+
+    class Work:
+        def wait(self):
+            return True
+
+    class FakeDist:                                # rank 0 of `world`: every rank sends what this GPU holds
+        @staticmethod
+        def gather(src, glist, dst=0, async_op=False):
+            for g in glist:
+                g.copy_(src, non_blocking=True)
+            return Work()
+
+    def query_chunk(lo, hi):
+        tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
+                         d_pml.data_ptr(), d_cid.data_ptr(), 2, stream.cuda_stream)
+
+    codec = multi_gpu.PmlCodec(
+        d_zero.view(torch.uint8),
+        lambda lo_base, n: pkg.pml_pack_device(d_pml.data_ptr() + 2 * lo_base, n, d_zero.data_ptr() + 4 * (lo_base // 32),
+                                               stream.cuda_stream),
+        lambda r, w0, nw: pkg.pml_unpack_device(g_zero[r].data_ptr(), d_end.data_ptr(), w0, nw, words,
+                                                g_pml[r].data_ptr(), comm.cuda_stream),
+        g_zero)
+    pipe = multi_gpu.GatherPipeline(FakeDist, 0, world, n_reads, m, 4, [(d_cid[:nb], 1)], dev, (stream, comm),
+                                    pml_codec=codec)
+    assert pipe.bounds[0] == 0 and pipe.bounds[-1] == n_reads and all(b % 32 == 0 for b in pipe.bounds[:-1])
+    for _ in range(2):
+        pipe.step(query_chunk)
+    torch.cuda.synchronize()
+    hb = d_bases[:nb].cpu().numpy()
+    ho = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(m)
+    ep, ec = oracle.OracleIndex(image.tobytes()).query_batch(hb, ho, threads=8)
+    assert np.array_equal(d_pml[:nb].cpu().numpy().view(np.uint16), ep)
+    for r in range(world):
+        assert np.array_equal(g_pml[r][:nb].cpu().numpy().view(np.uint16), ep), r
+        assert np.array_equal(pipe.gathered[0][r].cpu().numpy(), ec), r
+    tbl.close()

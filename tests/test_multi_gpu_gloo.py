@@ -21,7 +21,19 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_reads, m, n_chunks, q):
+def _np_unpack(zero_bits, end_bits):
+    """Reference of csrc/gather_codec.hip: pml[k] = j - k + (zero[j] ? 0 : 1), j = next stop >= k."""
+    n = len(zero_bits)
+    out = np.zeros(n, np.uint16)
+    j, add = -1, 0
+    for k in range(n - 1, -1, -1):
+        if zero_bits[k] or end_bits[k]:
+            j, add = k, 0 if zero_bits[k] else 1
+        out[k] = j - k + add if j >= 0 else 0
+    return out
+
+
+def _worker(rank, world, port, n_reads, m, n_chunks, q, packed=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -46,26 +58,54 @@ def _worker(rank, world, port, n_reads, m, n_chunks, q):
         pml[lo * m:hi * m] = torch.from_numpy(p.view(np.int16))
         cid[lo * m:hi * m] = torch.from_numpy(c)
 
-    pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
-                                    [(pml.view(torch.uint8), 2), (cid, 1)], torch.device("cpu"))
-    pipe.step(query_chunk)
+    if not packed:
+        pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
+                                        [(pml.view(torch.uint8), 2), (cid, 1)], torch.device("cpu"))
+        pipe.step(query_chunk)
+        gp = pipe.gathered[0].reshape(-1).numpy().view(np.uint16) if rank == 0 else None
+        gc = pipe.gathered[1].reshape(-1).numpy() if rank == 0 else None
+    else:
+        # the bit-per-base PML gather, numpy standing in for the codec kernels
+        nb = n_reads * m
+        words = (nb + 31) // 32
+        mask = torch.zeros(4 * words, dtype=torch.uint8)
+        gmask = torch.zeros((world, 4 * words), dtype=torch.uint8) if rank == 0 else None
+        gpml = np.zeros((world, words * 32), np.uint16)
+        end_bits = np.zeros(words * 32, bool)
+        end_bits[np.arange(1, n_reads + 1) * m - 1] = True
+
+        def pack(lo_base, n):
+            assert lo_base % 32 == 0
+            z = (pml[lo_base:lo_base + n].numpy() == 0)
+            z = np.concatenate((z, np.zeros((-n) % 32, bool)))
+            mask[lo_base // 8:lo_base // 8 + len(z) // 8] = torch.from_numpy(np.packbits(z, bitorder="little"))
+
+        def unpack(r, w0, nw):
+            zb = np.unpackbits(gmask[r].numpy(), bitorder="little").astype(bool)
+            assert end_bits[min(32 * (w0 + nw), nb) - 1]          # a chunk ends at a read end
+            gpml[r, 32 * w0:32 * (w0 + nw)] = _np_unpack(zb[:32 * (w0 + nw)], end_bits[:32 * (w0 + nw)])[32 * w0:]
+
+        codec = multi_gpu.PmlCodec(mask, pack, unpack, gmask)
+        pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, [(cid, 1)], torch.device("cpu"),
+                                        pml_codec=codec)
+        pipe.step(query_chunk)
+        gp = gpml[:, :nb].reshape(-1) if rank == 0 else None
+        gc = pipe.gathered[0].reshape(-1).numpy() if rank == 0 else None
     if rank == 0:
         all_bases, all_off = helpers.concat_reads(reads)
         ep, ec = ref.query_batch(all_bases, all_off)
-        gp = pipe.gathered[0].reshape(-1).numpy().view(np.uint16)
-        gc = pipe.gathered[1].reshape(-1).numpy()
         q.put(bool(np.array_equal(gp, ep) and np.array_equal(gc, ec)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_chunks", [1, 3])
-def test_two_rank_gather_matches_single_rank(n_chunks):
+@pytest.mark.parametrize("n_chunks,n_reads,packed", [(1, 40, False), (3, 40, False), (1, 40, True), (3, 100, True)])
+def test_two_rank_gather_matches_single_rank(n_chunks, n_reads, packed):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 40, 50, n_chunks, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_reads, 50, n_chunks, q, packed)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -89,3 +129,4 @@ def test_shard_reads_balances_bases():
         assert max(per) - min(per) <= 2 * 500
     assert multi_gpu.chunk_bounds(10, 4) == [0, 2, 5, 7, 10]
     assert multi_gpu.chunk_bounds(0, 4) == [0, 0]
+    assert multi_gpu.chunk_bounds(100, 4, 32) == [0, 32, 64, 100] and multi_gpu.chunk_bounds(40, 3, 32) == [0, 40]
