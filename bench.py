@@ -142,6 +142,7 @@ def main():
         pipe.step(query_chunk, timing_hook if record else None)
 
     def fence():
+        pipe.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -57,7 +57,9 @@ class PmlCodec:
 
 
 class GatherPipeline:
-    """Per-step driver: query chunk c, then gather it while chunk c+1 computes.
+    """Per-step driver: query chunk c, then gather it while the following chunks -- of
+    this step and of the next -- compute; a chunk's buffers are only reused once its
+    previous gather has finished.  Call finish() before reading the results.
 
     query_chunk(lo, hi) launches the query for reads [lo, hi) of this rank's
     shard on the current stream (asynchronously on a GPU).  `outputs` is a list
@@ -79,14 +81,18 @@ class GatherPipeline:
         self.cuda = device.type == "cuda"
         self.compute_stream, self.comm_stream = streams if streams else (None, None)
         self.gathered = None
+        self.pending = [[] for _ in range(len(self.bounds) - 1)]   # per chunk: gathers still reading it
         if world > 1 and rank == 0:
             self.gathered = [torch.empty((world, t.numel()), dtype=torch.uint8, device=device) for t, _ in outputs]
 
     def step(self, query_chunk, on_launch=None):
         torch, dist = self.torch, self.dist
-        works = []
         for c in range(len(self.bounds) - 1):
             lo, hi = self.bounds[c], self.bounds[c + 1]
+            works = self.pending[c]
+            for w in works:              # the compute stream waits for last step's gather of this chunk
+                w.wait()
+            del works[:]
             if on_launch:
                 on_launch("before")
             query_chunk(lo, hi)
@@ -119,8 +125,14 @@ class GatherPipeline:
                         work.wait()          # orders the comm stream behind the gather (blocks on gloo)
                         for r in range(self.world):
                             self.codec.unpack(r, w0, w1 - w0)
-        for w in works:
-            w.wait()
+
+    def finish(self):
+        """Waits for every outstanding gather (and, on a GPU, orders the compute stream behind the
+        side stream's decode kernels)."""
+        for works in self.pending:
+            for w in works:
+                w.wait()
+            del works[:]
         if self.cuda and self.comm_stream is not None and self.world > 1:
             self.compute_stream.wait_stream(self.comm_stream)
 

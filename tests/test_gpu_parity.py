@@ -433,6 +433,7 @@ def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
     assert pipe.bounds[0] == 0 and pipe.bounds[-1] == n_reads and all(b % 32 == 0 for b in pipe.bounds[:-1])
     for _ in range(2):
         pipe.step(query_chunk)
+    pipe.finish()
     torch.cuda.synchronize()
     hb = d_bases[:nb].cpu().numpy()
     ho = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(m)

@@ -62,6 +62,8 @@ def _worker(rank, world, port, n_reads, m, n_chunks, q, packed=False):
         pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks,
                                         [(pml.view(torch.uint8), 2), (cid, 1)], torch.device("cpu"))
         pipe.step(query_chunk)
+        pipe.step(query_chunk)      # buffers are reused across steps
+        pipe.finish()
         gp = pipe.gathered[0].reshape(-1).numpy().view(np.uint16) if rank == 0 else None
         gc = pipe.gathered[1].reshape(-1).numpy() if rank == 0 else None
     else:
@@ -89,6 +91,8 @@ def _worker(rank, world, port, n_reads, m, n_chunks, q, packed=False):
         pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, [(cid, 1)], torch.device("cpu"),
                                         pml_codec=codec)
         pipe.step(query_chunk)
+        pipe.step(query_chunk)      # buffers are reused across steps
+        pipe.finish()
         gp = gpml[:, :nb].reshape(-1) if rank == 0 else None
         gc = pipe.gathered[0].reshape(-1).numpy() if rank == 0 else None
     if rank == 0:
