@@ -32,6 +32,16 @@ using namespace colbwt;
 
 struct colbwt_index {
     Index ix;
+    // Two pinned staging buffers for results that go to pageable host memory (kept for the
+    // life of the handle: pinning costs as much as a copy).  One caller at a time uses them;
+    // concurrent callers fall back to the runtime's own pageable copy.
+    std::mutex stage_mu;
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    ~colbwt_index() {
+        for (void *p : stage)
+            if (p) (void)hipHostFree(p);
+    }
 };
 
 namespace {
@@ -78,6 +88,83 @@ struct MappedFile {
         return true;
     }
 };
+
+constexpr size_t kStageBytes = 128u << 20;     // per staging buffer
+constexpr size_t kStageMinTotal = 256u << 20;  // smaller results: the plain copy is as good
+constexpr unsigned kStageThreads = 8;
+
+bool is_pageable(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) == hipSuccess)                 // ROCm >= 6 knows plain host memory
+        return a.type == hipMemoryTypeUnregistered;                   // else pinned / registered / device
+    (void)hipGetLastError();                                          // older answer: "invalid value"
+    return true;
+}
+
+void parallel_memcpy(uint8_t *dst, const uint8_t *src, size_t n) {
+    if (n < (8u << 20)) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::thread ts[kStageThreads - 1];
+    const size_t per = (n / kStageThreads + 4095) & ~(size_t)4095;
+    for (unsigned t = 1; t < kStageThreads; ++t) {
+        const size_t a = std::min(n, per * t), b = std::min(n, per * (t + 1));
+        ts[t - 1] = std::thread([=] { if (b > a) memcpy(dst + a, src + a, b - a); });
+    }
+    memcpy(dst, src, std::min(n, per));
+    for (auto &th : ts) th.join();
+}
+
+struct D2HSegment {
+    uint8_t *dst;
+    const uint8_t *src;
+    size_t bytes;
+};
+
+// Device -> pageable host memory through the handle's two pinned buffers: the DMA of chunk
+// k runs while host threads copy chunk k-1 out of its buffer.  Returns hipSuccess or the
+// first HIP error; the stream is idle afterwards.
+hipError_t staged_d2h(colbwt_index *idx, const D2HSegment *seg, int n_seg, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    if (!idx->stage[0]) {
+        for (int b = 0; b < 2; ++b) {
+            e = hipHostMalloc(&idx->stage[b], kStageBytes, 0);
+            if (e != hipSuccess) {
+                idx->stage[b] = nullptr;
+                return e;
+            }
+        }
+        idx->stage_bytes = kStageBytes;
+    }
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (auto &x : ev)
+        if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
+    struct Piece {
+        uint8_t *dst;
+        size_t n;
+    } prev{nullptr, 0};
+    int k = 0;
+    for (int s = 0; s < n_seg && e == hipSuccess; ++s) {
+        for (size_t o = 0; o < seg[s].bytes && e == hipSuccess; o += kStageBytes, ++k) {
+            const size_t n = std::min(kStageBytes, seg[s].bytes - o);
+            e = hipMemcpyAsync(idx->stage[k & 1], seg[s].src + o, n, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(ev[k & 1], stream);
+            if (prev.dst && e == hipSuccess) {
+                e = hipEventSynchronize(ev[(k - 1) & 1]);
+                if (e == hipSuccess) parallel_memcpy(prev.dst, (const uint8_t *)idx->stage[(k - 1) & 1], prev.n);
+            }
+            prev = Piece{seg[s].dst + o, n};
+        }
+    }
+    if (prev.dst && e == hipSuccess) {
+        e = hipEventSynchronize(ev[(k - 1) & 1]);
+        if (e == hipSuccess) parallel_memcpy(prev.dst, (const uint8_t *)idx->stage[(k - 1) & 1], prev.n);
+    }
+    const hipError_t e2 = hipStreamSynchronize(stream);
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    return e != hipSuccess ? e : e2;
+}
 
 template <typename PmlT>
 int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, PmlT *pml,
@@ -151,8 +238,22 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     API_HIP(hipGetLastError());
     API_HIP(hipEventRecord(ev[2], stream));
-    API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
-    API_HIP(hipMemcpyAsync(cid, d_cid, n_bases, hipMemcpyDeviceToHost, stream));
+    {
+        // results into pageable memory go through pinned staging buffers with several copier
+        // threads (the runtime's own pageable path manages ~17 GB/s); pinned destinations and
+        // small batches are copied directly
+        std::unique_lock<std::mutex> stage_lock(idx->stage_mu, std::defer_lock);
+        const bool staged = n_bases * (sizeof(PmlT) + 1) >= kStageMinTotal && is_pageable(pml) && is_pageable(cid) &&
+                            stage_lock.try_lock();
+        if (staged) {
+            const D2HSegment seg[2] = {{(uint8_t *)pml, (const uint8_t *)d_pml, n_bases * sizeof(PmlT)},
+                                       {cid, d_cid, n_bases}};
+            API_HIP(staged_d2h(idx, seg, 2, stream));
+        } else {
+            API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
+            API_HIP(hipMemcpyAsync(cid, d_cid, n_bases, hipMemcpyDeviceToHost, stream));
+        }
+    }
     API_HIP(hipEventRecord(ev[3], stream));
     API_HIP(hipStreamSynchronize(stream));
     API_HIP(hipEventElapsedTime(&ms_h2d, ev[0], ev[1]));

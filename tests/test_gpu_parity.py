@@ -443,3 +443,30 @@ def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
         assert np.array_equal(g_pml[r][:nb].cpu().numpy().view(np.uint16), ep), r
         assert np.array_equal(pipe.gathered[0][r].cpu().numpy(), ec), r
     tbl.close()
+
+
+def test_host_entry_large_batch_uses_staged_copy(pkg):
+    """colbwt_query_batch with > 256 MB of results in pageable memory: the results come back
+    through the pinned staging buffers (several 128 MB chunks, two buffers alternating) and
+    must equal what the device entry point left in HBM."""
+    import torch
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(2_000_000, mean_len=8, seed=12)
+    tbl = pkg.ColPml.from_bytes(image.tobytes())
+    n_reads, m = 2_200_003, 150
+    nb = n_reads * m
+    d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    tbl.synth_reads_device(n_reads, m, 15, 5, d_bases.data_ptr(), d_off.data_ptr())
+    d_pml = torch.zeros(nb + 16, dtype=torch.int16, device=dev)
+    d_cid = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
+    tbl.query_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, nb, d_pml.data_ptr(), d_cid.data_ptr())
+    torch.cuda.synchronize()
+    bases = d_bases[:nb].cpu().numpy()
+    off = d_off.cpu().numpy().astype(np.uint64)
+    for _ in range(2):                                   # second call reuses the staging buffers
+        pml, cid, st = tbl.query_batch(bases, off)
+        assert st.n_bases == nb
+        assert np.array_equal(pml.view(np.int16), d_pml[:nb].cpu().numpy())
+        assert np.array_equal(cid, d_cid[:nb].cpu().numpy())
+    tbl.close()
