@@ -63,11 +63,46 @@ def lf_columns(chars, idx, n):
     return interval.astype(np.uint64), offset.astype(np.uint64)
 
 
+def _index_from_bwt_lcp(bwt, lcp, rng, extra_splits, ids):
+    """Run heads, thresholds = position of the minimum LCP between consecutive runs of a
+    character (0 for a character's first run), random sub-run splits and ids -> image bytes."""
+    n = len(bwt)
+    heads = np.flatnonzero(np.concatenate(([True], bwt[1:] != bwt[:-1])))
+    bwt_r = len(heads)
+    ends = np.append(heads[1:], n) - 1                       # last position of every run
+    run_thr = np.zeros(bwt_r, np.int64)
+    key = lcp.astype(np.int64) * n + np.arange(n)            # min key = (min lcp, first position)
+    head_chars = bwt[heads]
+    for c in np.unique(head_chars):
+        runs = np.flatnonzero(head_chars == c)
+        if len(runs) < 2:
+            continue
+        lo = ends[runs[:-1]] + 1                             # first position after the previous c-run
+        hi = heads[runs[1:]] + 1                             # one past this run's head
+        cuts = np.empty(2 * len(lo), np.int64)
+        cuts[0::2], cuts[1::2] = lo, hi
+        keep = cuts < n
+        mins = np.minimum.reduceat(key, cuts[keep])
+        run_thr[runs[1:]] = (mins[0::2] % n)[:len(lo)]
+    split = np.zeros(n, bool)
+    split[heads] = True
+    cand = np.flatnonzero(~split)
+    if len(cand) and extra_splits:
+        split[rng.choice(cand, size=min(extra_splits, len(cand)), replace=False)] = True
+    starts = np.flatnonzero(split).astype(np.int64)
+    chars = bwt[starts]
+    run_of = np.searchsorted(heads, starts, side="right") - 1
+    thr = run_thr[run_of]
+    cid = rng.choice(np.array(ids, np.uint8), size=len(starts))
+    interval, offset = lf_columns(chars, starts, n)
+    return pack_col_pml(bwt_r, n, chars, starts, interval, offset, cid, thr)
+
+
 def true_bwt_index(seqs, seed=0, extra_splits=20, ids=(0, 0, 0, 1, 2, 3, 17, 200, 255), term=1):
     """A real BWT index of concat(seqs)+terminator: suffix array by sorting,
     run heads, thresholds = min-LCP position between consecutive same-char
     runs (0 for the first run of a character), random sub-run splits and ids.
-    Returns (image_bytes, text_bytes)."""
+    Returns (image_bytes, text_bytes).  Quadratic: small texts only."""
     rng = np.random.default_rng(seed)
     text = b"".join(seqs) + bytes([term])
     n = len(text)
@@ -80,29 +115,46 @@ def true_bwt_index(seqs, seed=0, extra_splits=20, ids=(0, 0, 0, 1, 2, 3, 17, 200
         while l < len(a) and l < len(b) and a[l] == b[l]:
             l += 1
         lcp[k] = l
-    heads = np.flatnonzero(np.concatenate(([True], bwt[1:] != bwt[:-1])))
-    bwt_r = len(heads)
-    run_thr = np.zeros(bwt_r, np.int64)
-    last_end = {}
-    for k, h in enumerate(heads):
-        c = int(bwt[h])
-        if c in last_end:
-            lo = last_end[c] + 1           # first position after the previous c-run
-            seg = lcp[lo:h + 1]
-            run_thr[k] = lo + int(np.argmin(seg))
-        end = heads[k + 1] - 1 if k + 1 < bwt_r else n - 1
-        last_end[c] = end
-    split = set(heads.tolist())
-    cand = [p for p in range(n) if p not in split]
-    if cand and extra_splits:
-        split.update(rng.choice(cand, size=min(extra_splits, len(cand)), replace=False).tolist())
-    starts = np.array(sorted(split), np.int64)
-    chars = bwt[starts]
-    run_of = np.searchsorted(heads, starts, side="right") - 1
-    thr = run_thr[run_of]
-    cid = rng.choice(np.array(ids, np.uint8), size=len(starts))
-    interval, offset = lf_columns(chars, starts, n)
-    return pack_col_pml(bwt_r, n, chars, starts, interval, offset, cid, thr), text
+    return _index_from_bwt_lcp(bwt, lcp, rng, extra_splits, ids), text
+
+
+def true_bwt_index_large(seqs, seed=0, extra_splits=20, ids=(0, 0, 0, 1, 2, 3, 17, 200, 255), term=1):
+    """The same index as true_bwt_index for texts of millions of characters (BASELINE.json's
+    C1 shape): suffix array by prefix doubling, LCP by binary lifting over the rank arrays of
+    the doubling rounds, all in numpy.  The terminator must be the smallest byte and unique."""
+    rng = np.random.default_rng(seed)
+    text = b"".join(seqs) + bytes([term])
+    t = np.frombuffer(text, np.uint8)
+    n = len(t)
+    assert (t[:-1] > term).all()
+    rank = t.astype(np.int64)
+    ranks = []                                   # ranks[j] orders suffixes by their first 2^j characters
+    k = 1
+    while True:
+        ranks.append(rank)
+        if rank.max() == n - 1 and len(np.unique(rank)) == n:
+            break
+        nxt = np.full(n, -1, np.int64)           # beyond the end sorts first (cannot tie: unique terminator)
+        nxt[:n - k] = rank[k:]
+        order = np.lexsort((nxt, rank))
+        r_s, n_s = rank[order], nxt[order]
+        new = np.concatenate(([0], np.cumsum((r_s[1:] != r_s[:-1]) | (n_s[1:] != n_s[:-1]))))
+        rank = np.empty(n, np.int64)
+        rank[order] = new
+        k *= 2
+    sa = np.empty(n, np.int64)
+    sa[ranks[-1]] = np.arange(n)
+    bwt = t[(sa - 1) % n]
+    a, b = sa[:-1], sa[1:]
+    l = np.zeros(n - 1, np.int64)
+    for j in range(len(ranks) - 2, -1, -1):      # ranks[-1] is unique; level j compares 2^j characters
+        ia, ib = a + l, b + l
+        ok = (ia < n) & (ib < n)
+        same = np.zeros(n - 1, bool)
+        same[ok] = ranks[j][ia[ok]] == ranks[j][ib[ok]]
+        l += same * (1 << j)
+    lcp = np.concatenate(([0], l))
+    return _index_from_bwt_lcp(bwt, lcp, rng, extra_splits, ids), text
 
 
 def random_table(rng, r, alphabet=b"ACGT", max_len=9, split_prob=0.1, thr_inside=True):

@@ -80,6 +80,27 @@ def test_true_bwt_index_ragged_reads(pkg, oracle):
     _check(pkg, oracle, image, reads)
 
 
+def test_c1_four_related_megabase_sequences(pkg, oracle):
+    """BASELINE.json configs[0] (C1): 4 x 1 Mbp sequences (one random, three copies with 1 %
+    SNPs), their true BWT with min-LCP thresholds and sub-run splits, 10 k x 100 bp reads with
+    1 % substitutions -- a real run-length / threshold structure at scale, all HBM layouts."""
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = rng.choice(acgt, size=1_000_000)
+    seqs = [bytes(base)]
+    for k in range(3):
+        s = base.copy()
+        mut = rng.random(len(s)) < 0.01
+        s[mut] = rng.choice(acgt, size=int(mut.sum()))
+        seqs.append(bytes(s))
+    image, text = helpers.true_bwt_index_large(seqs, seed=2, extra_splits=20_000)
+    t = helpers.unpack_col_pml(image)
+    assert t["n"] == 4_000_001 and t["r"] > 100_000
+    reads = helpers.reads_from_text(text, 10_000, 100, 0.01, seed=5)
+    st = _check(pkg, oracle, image, reads)
+    assert st.n_bases == 1_000_000
+
+
 def test_empty_batch_and_all_empty_reads(pkg):
     tbl = pkg.ColPml.from_bytes(pkg.synth_index(400, 5, 0, 1))
     pml, cid, _ = tbl.query_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))

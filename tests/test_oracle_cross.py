@@ -48,3 +48,21 @@ def test_synthetic_rows(oracle, pkg):
         reads = helpers.backward_walk_reads(image, 10, 60, 0.03, seed=7)
         reads += [rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(m)) for m in rng.integers(1, 50, size=10)]
         _compare(oracle, image, reads)
+
+
+def test_large_index_builder_equals_the_naive_one():
+    """tests/helpers.true_bwt_index_large (prefix doubling + rank lifting, used for the C1-shaped
+    GPU test) against the quadratic textbook construction on a small text."""
+    import helpers
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    base = rng.choice(acgt, size=400)
+    seqs = []
+    for _ in range(4):
+        s = base.copy()
+        mut = rng.random(len(s)) < 0.03
+        s[mut] = rng.choice(acgt, size=int(mut.sum()))
+        seqs.append(bytes(s))
+    a, ta = helpers.true_bwt_index(seqs, seed=5, extra_splits=30)
+    b, tb = helpers.true_bwt_index_large(seqs, seed=5, extra_splits=30)
+    assert ta == tb and bytes(a) == bytes(b)
