@@ -118,16 +118,10 @@ void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_
         if (o != kOffPred && o != kOffSucc) {
             const uint32_t len = sk_len<K>(w);
             if (o >= len && j < T.r - 1) {
-                // fast-forward of LF_table::LF (LF_table.hpp:256-259) over level-K rows, two rows
-                // per trip (a row carries the next row's length)
+                // fast-forward of LF_table::LF (LF_table.hpp:256-259) over level-K rows: one row
+                // per trip (the first step of most of them was taken at the jump, see sk_cut)
                 o -= len;
-                uint32_t hop = 1;
-                const uint32_t l1 = sk_len8_next1<K>(w);
-                if (l1 != kLen8Long && o >= l1 && j + 1 < T.r - 1) {
-                    o -= l1;
-                    hop = 2;
-                }
-                j += hop;
+                j += 1;
                 jump = false;
             } else {
                 o = o < len ? o : len - 1;
@@ -182,8 +176,14 @@ void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_
         look(sk_char_at<K, 2>(w), sk_cid_at<K, 2>(w), 2);
         if constexpr (K >= 3) look(sk_char_at<K, 3>(w), sk_cid_at<K, 3>(w), 3);
         if (k == 0) break;
-        o += sk_O<K>(w, steps);                              // LF^steps lands at (I_s, O_s + o)
-        j = sk_I<K>(w, steps);
+        j = sk_I<K>(w, steps);                               // LF^steps lands at (I_s, O_s + o) ...
+        const uint32_t cut = sk_cut<K>(w);
+        if (steps == (uint32_t)K && cut != kSKCutNone && o >= cut) {
+            j += 1;                                          // ... which is already in the next row
+            o -= cut;
+        } else {
+            o += sk_O<K>(w, steps);
+        }
     }
     if constexpr (!kWide) {                                  // k == 0: what the last trip pushed
         acc.flush_group((uint16_t *)pml, cid, off);
