@@ -263,6 +263,25 @@ def main():
         }
         if not parity:
             out["error"] = "GPU output differs from the oracle on the CPU sample"
+        # ---- the kernel's real ceiling, measured on THIS box (it varies by a few percent from
+        #      box to box): dependent random 2 x 16-byte loads per 128-byte line of a 16 GiB table
+        #      (tools/gather_bench, a child process; skipped together with the CPU leg, e.g. under
+        #      rocprofv3).  Replaces the constant taken from profiles/.
+        lf = out["roofline"].get("line_fills")
+        gb = os.path.join(ROOT, "tools", "gather_bench")
+        if lf and os.path.exists(gb):
+            try:
+                import subprocess
+                res = subprocess.run([gb, "16384", "524288", "1500", "3", "2", "0"], capture_output=True, text=True,
+                                     timeout=120)
+                rates = [json.loads(line)["Gsteps_per_s"] for line in res.stdout.splitlines() if line.startswith("{")]
+                if rates:
+                    lf["ceiling_G_per_s"] = max(rates)
+                    lf["frac"] = lf["achieved_G_per_s"] / lf["ceiling_G_per_s"]
+                    lf["ceiling_source"] = "tools/gather_bench on this box, after the timed region " \
+                                           "(dependent random 2x16 B loads per line, 16 GiB table)"
+            except Exception as e:      # the calibration is optional: keep the recorded constant
+                lf["ceiling_note"] = f"live calibration failed: {e}"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
