@@ -197,10 +197,13 @@ def main():
             if info.layout == 3 and tj.get("read_requests_per_launch"):
                 # What actually bounds the kernel: the chip's rate of random
                 # 128-byte line fills, measured by tools/gather_littles.sh for this access shape.
-                req = tj["read_requests_per_launch"] + tj["write_requests_per_launch"]
-                line_fills = {"requests_per_launch": req, "achieved_G_per_s": req / (avg_launch_ms * 1e-3) / 1e9,
-                              "ceiling_G_per_s": GATHER_CEILING_G, "frac": req / (avg_launch_ms * 1e-3) / 1e9 / GATHER_CEILING_G,
-                              "ceiling_source": "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B loads per line)"}
+                rd, wr = tj["read_requests_per_launch"], tj["write_requests_per_launch"]
+                sec = avg_launch_ms * 1e-3
+                line_fills = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
+                              "achieved_G_per_s": rd / sec / 1e9, "write_G_per_s": wr / sec / 1e9,
+                              "ceiling_G_per_s": GATHER_CEILING_G, "frac": rd / sec / 1e9 / GATHER_CEILING_G,
+                              "ceiling_source": "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B "
+                                                "loads per line, reads only)"}
         out = {
             "metric": "query bases/s", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -279,7 +282,7 @@ def main():
                     lf["ceiling_G_per_s"] = max(rates)
                     lf["frac"] = lf["achieved_G_per_s"] / lf["ceiling_G_per_s"]
                     lf["ceiling_source"] = "tools/gather_bench on this box, after the timed region " \
-                                           "(dependent random 2x16 B loads per line, 16 GiB table)"
+                                           "(dependent random 2x16 B loads per line, 16 GiB table, reads only)"
             except Exception as e:      # the calibration is optional: keep the recorded constant
                 lf["ceiling_note"] = f"live calibration failed: {e}"
     if rank == 0:
