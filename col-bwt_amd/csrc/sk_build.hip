@@ -286,13 +286,20 @@ __global__ __launch_bounds__(256) void sk_link_kernel(Src S, const uint32_t *__r
         p[kO] = (O[0] & 0xFFFFu) | (O[1] << 16);
         p[kO + 1] = (p[kO + 1] & 0xFFFF0000u) | (O[2] & 0xFFFFu);
     }
-    // where the image under the deepest jump, LF^K, leaves its landing row: offsets >= cut land
-    // in the row after I[K] (sk_layout.h); distances stay "far" until the hint pass
-    uint32_t cut = kSKCutNone;
-    if (I[K - 1] + 1 < r_new) {
+    // where the image under the deepest jump, LF^K, leaves its landing row and the row after it
+    // (sk_layout.h); distances stay "far" until the hint pass
+    uint32_t cut = kSKCutNone, len_b = kSKCutNone;
+    if ((uint64_t)I[K - 1] + 1 < r_new) {
         const uint64_t c = idx_new[(uint64_t)I[K - 1] + 1] - idx_new[I[K - 1]] - O[K - 1];
-        if (c < kSKCutNone) cut = (uint32_t)c;
+        if (c < kSKCutNone) {
+            cut = (uint32_t)c;
+            if ((uint64_t)I[K - 1] + 2 < r_new) {
+                const uint64_t l = idx_new[(uint64_t)I[K - 1] + 2] - idx_new[(uint64_t)I[K - 1] + 1];
+                if (l < kSKCutNone) len_b = (uint32_t)l;
+            }
+        }
     }
+    cut |= len_b << 4;
     p[kL + 1] = cut | 0xFFFFFF00u;
     p[kL + 2] |= 0xFFu;
 }

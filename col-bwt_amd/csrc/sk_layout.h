@@ -19,12 +19,13 @@
 //   I[1..K]   level-K row holding LF^s(first position of the row)
 //   O[1..K]   16-bit offsets of those images inside I[s]
 //   len16 | char << 16 | col_id << 24                  (len <= 65534 by construction)
-//   cut8 | 3 x 8-bit mismatch-target distances (hint slots 0..2) << 8
-//             cut8: the image of this row under the deepest jump LF^K starts at offset O[K]
-//             of row I[K]; positions at offsets >= cut8 = len(I[K]) - O[K] fall into row
-//             I[K] + 1, at offset - cut8 (255: the whole image, or at least its first 255
-//             positions, stay in I[K]).  Most landings that would fast-forward (LF_table.hpp:
-//             256-259) need exactly this one step, and 2/3 of the jumps are the deepest.
+//   cuts | 3 x 8-bit mismatch-target distances (hint slots 0..2) << 8
+//             cuts = cut_a | len_b << 4 (4 bits each, 15 = none): the image of this row under
+//             the deepest jump LF^K starts at offset O[K] of row I[K]; positions at offsets
+//             >= cut_a = len(I[K]) - O[K] fall into row I[K] + 1 at offset - cut_a, and those
+//             at >= len_b = len(I[K] + 1) there into row I[K] + 2.  Two thirds of the jumps are
+//             the deepest, 4 in 10 of those leave their landing row, nearly all by one or two
+//             short rows: these steps of the fast-forward (LF_table.hpp:256-259) cost no load.
 //   distance of slot 3 | char2 << 8 | col_id2 << 16 | hints << 24 ;  K = 3: char3, col_id3
 //             (distances as in the one-step layout, device_layout.h, but 8 bits
 //             wide, 255 = scan: refined rows put the target run up to K times
@@ -43,7 +44,7 @@ namespace colbwt {
 
 constexpr uint32_t kSKMaxLen = 65534;   // longer rows are cut (legal by B.3)
 constexpr uint32_t kSKDistFar = 255u;   // 8-bit distance escape
-constexpr uint32_t kSKCutNone = 255u;   // 8-bit cut escape
+constexpr uint32_t kSKCutNone = 15u;    // 4-bit cut escape
 
 template <int K>
 struct SKGeom;
@@ -127,7 +128,9 @@ __device__ __forceinline__ uint32_t sk_char(const SKRow<K> &w) { return (w.d[SKG
 template <int K>
 __device__ __forceinline__ uint32_t sk_cid(const SKRow<K> &w) { return w.d[SKGeom<K>::kLen] >> 24; }
 template <int K>
-__device__ __forceinline__ uint32_t sk_cut(const SKRow<K> &w) { return w.d[SKGeom<K>::kLen + 1] & 0xFFu; }
+__device__ __forceinline__ uint32_t sk_cut_a(const SKRow<K> &w) { return w.d[SKGeom<K>::kLen + 1] & 0xFu; }
+template <int K>
+__device__ __forceinline__ uint32_t sk_len_b(const SKRow<K> &w) { return (w.d[SKGeom<K>::kLen + 1] >> 4) & 0xFu; }
 template <int K>
 __device__ __forceinline__ uint32_t sk_dist(const SKRow<K> &w, uint32_t slot) {   // slot in [0, 3]
     const uint32_t three = w.d[SKGeom<K>::kLen + 1] >> 8;                        // slots 0..2

@@ -177,10 +177,15 @@ void sk_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64_
         if constexpr (K >= 3) look(sk_char_at<K, 3>(w), sk_cid_at<K, 3>(w), 3);
         if (k == 0) break;
         j = sk_I<K>(w, steps);                               // LF^steps lands at (I_s, O_s + o) ...
-        const uint32_t cut = sk_cut<K>(w);
+        const uint32_t cut = sk_cut_a<K>(w);
         if (steps == (uint32_t)K && cut != kSKCutNone && o >= cut) {
             j += 1;                                          // ... which is already in the next row
             o -= cut;
+            const uint32_t lb = sk_len_b<K>(w);
+            if (lb != kSKCutNone && o >= lb) {               // ... or in the one after
+                j += 1;
+                o -= lb;
+            }
         } else {
             o += sk_O<K>(w, steps);
         }
