@@ -2,7 +2,7 @@
 """Query rate on a TRUE BWT index of H related sequences (a pangenome in miniature: long
 runs, min-LCP thresholds), built by the test helpers' numpy suffix-array construction.
 
-    python tools/true_bwt_bench.py [--haplotypes 32 --length 1000000 --reads 2000000]
+    python tests/bench_true_bwt.py [--haplotypes 32 --length 1000000 --reads 2000000]
 The index is small (it fits the caches) -- this measures the kernel on a realistic run /
 threshold structure, not the HBM-bound C2 regime; results are checked against the oracle
 on a sample.
@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # lives under tests/: it calls the oracle as checker
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 import helpers  # noqa: E402
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extended randomised parity sweep on the GPU box (beyond the 50 tables of the -m gpu suite):
-    python tools/fuzz_more.py <first_seed> <last_seed>     # steps of 25 seeds, 3 layouts each
+    python tests/fuzz_more.py <first_seed> <last_seed>     # steps of 25 seeds, 3 layouts each
 """
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
