@@ -10,9 +10,12 @@
 //       .x  interval                      (32)   LF_row::interval
 //       .y  offset | len16 << 16          (16+16) LF_row::offset ; run length,
 //                                          0xFFFF = "long": idx[j+1]-idx[j]
-//       .z  len8 of row j+1 | len8 of row j+2 << 8 (0xFF = long / none): the
-//           fast-forward loop (LF_table.hpp:256-259) hops up to three rows per
-//           memory round trip instead of one;
+//       .z  cut_a | len_b << 8 (8 bits each, 0xFF = none): the LF image of this row starts
+//           at offset `offset` of row `interval`; positions at offsets >= cut_a =
+//           len(interval) - offset fall into row interval + 1 (at offset - cut_a), and
+//           those at >= cut_a + len_b (len_b = len(interval + 1)) into row interval + 2:
+//           the first steps of the fast-forward loop (LF_table.hpp:256-259) are taken
+//           before the landing row is loaded, not with extra dependent loads after it;
 //           | dist << 16: 4 bits per hint slot, the distance in rows to the run a
 //           mismatch on that character re-orients to (the predecessor when the
 //           hint says pred-side, else the successor; 15 = scan for it): a
@@ -50,7 +53,7 @@ constexpr uint32_t kAbsent = 0xFFu;         // cmap: byte not in the BWT
 constexpr uint32_t kAlgBytesPerBase = 27;
 constexpr uint32_t kHintPred = 0, kHintSucc = 1, kHintCompare = 2;
 constexpr uint32_t kHintAllCompare = 0xAAu; // every slot = kHintCompare
-constexpr uint32_t kLen8Long = 0xFFu;       // .z next-row length escape
+constexpr uint32_t kCutNone = 0xFFu;        // .z cut escape
 constexpr uint32_t kDistFar = 15u;          // .z distance nibble: target not within 14 rows / unknown
 constexpr uint32_t kHintSlots = 4;          // 2 bits each in the row's spare byte
 constexpr uint32_t kHintMaxSigma = 5;       // characters that can own a slot: the 5 most frequent

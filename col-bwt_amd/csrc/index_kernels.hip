@@ -73,10 +73,9 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         }
         const uint64_t len = next_idx - idx;
         const uint32_t len16 = len < kLenLong ? (uint32_t)len : kLenLong;
-        const uint64_t len1 = next2_idx - next_idx, len2 = next3_idx - next2_idx;
-        const uint32_t l1 = (i + 1 < r && next2_idx > next_idx && len1 < kLen8Long) ? (uint32_t)len1 : kLen8Long;
-        const uint32_t l2 = (i + 2 < r && next3_idx > next2_idx && len2 < kLen8Long) ? (uint32_t)len2 : kLen8Long;
-        rows[i] = make_uint4(interval, offset | (len16 << 16), l1 | (l2 << 8) | 0xFFFF0000u,
+        (void)next2_idx;
+        (void)next3_idx;
+        rows[i] = make_uint4(interval, offset | (len16 << 16), 0xFFFFFFFFu,   // cuts / distances: hint_kernel
                              (ch << 8) | (cid << 16) | (kHintAllCompare << 24));
         idx_out[i] = idx;
         thr[i] = threshold;
@@ -166,7 +165,23 @@ __global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, H
         }
         dists = (dists & ~(0xFu << (4 * slot))) | (dist << (4 * slot));
     }
-    rows_rw[i].z = (w.z & 0x0000FFFFu) | (dists << 16);
+    // Cuts of the LF jump (device_layout.h): the image of this row starts at offset O of row I;
+    // offsets >= cut_a = len(I) - O fall into row I + 1, those >= cut_a + len_b into row I + 2.
+    uint32_t cut_a = kCutNone, len_b = kCutNone;
+    {
+        const uint32_t I = row_interval(w);
+        if ((uint64_t)I + 1 < T.r) {
+            const uint64_t c = T.idx[(uint64_t)I + 1] - T.idx[I] - row_offset(w);
+            if (c < kCutNone) {
+                cut_a = (uint32_t)c;
+                if ((uint64_t)I + 2 < T.r) {
+                    const uint64_t l = T.idx[(uint64_t)I + 2] - T.idx[(uint64_t)I + 1];
+                    if (l < kCutNone) len_b = (uint32_t)l;
+                }
+            }
+        }
+    }
+    rows_rw[i].z = cut_a | (len_b << 8) | (dists << 16);
     rows_rw[i].w = (w.w & 0x00FFFFFFu) | (hints << 24);
 }
 

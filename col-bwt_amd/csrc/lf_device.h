@@ -15,8 +15,8 @@ namespace colbwt {
 __device__ __forceinline__ uint32_t row_interval(const uint4 &w) { return w.x; }
 __device__ __forceinline__ uint32_t row_offset(const uint4 &w) { return w.y & 0xFFFFu; }
 __device__ __forceinline__ uint32_t row_len16(const uint4 &w) { return w.y >> 16; }
-__device__ __forceinline__ uint32_t row_len8_next1(const uint4 &w) { return w.z & 0xFFu; }
-__device__ __forceinline__ uint32_t row_len8_next2(const uint4 &w) { return (w.z >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t row_cut_a(const uint4 &w) { return w.z & 0xFFu; }
+__device__ __forceinline__ uint32_t row_len_b(const uint4 &w) { return (w.z >> 8) & 0xFFu; }
 __device__ __forceinline__ uint32_t row_dist(const uint4 &w, uint32_t slot) { return (w.z >> (16 + 4 * slot)) & 0xFu; }
 __device__ __forceinline__ uint64_t row_idx(const DevTable &T, uint32_t j) { return T.idx[j]; }
 __device__ __forceinline__ uint32_t row_char(const uint4 &w) { return (w.w >> 8) & 0xFFu; }

@@ -160,27 +160,29 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
         if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
 
-        // LF_table::LF (LF_table.hpp:251-262).  A row also carries the lengths of the two rows
-        // after it, so the fast-forward (:256-259) hops up to three rows per memory round trip.
+        // LF_table::LF (LF_table.hpp:251-262).  The row knows where its image leaves the landing
+        // row and the row after it (cut_a, len_b), so the first steps of the fast-forward
+        // (:256-259) are taken before the load; the loop only runs for what is left.
         uint32_t j = row_interval(w);                // :253
-        uint64_t t = (uint64_t)row_offset(w) + o;    // :254
+        uint64_t t = o;
+        const uint32_t cut = row_cut_a(w);
+        if (cut != kCutNone && t >= cut) {
+            j += 1;
+            t -= cut;
+            const uint32_t lb = row_len_b(w);
+            if (lb != kCutNone && t >= lb) {
+                j += 1;
+                t -= lb;
+            }
+        } else {
+            t += row_offset(w);                      // :254
+        }
         w = T.rows[j];
         for (;;) {
             const uint64_t len = row_len(T, j, w);
             if (t < len || j >= T.r - 1) break;      // :256 (bounded: a validated table never passes r-1)
             t -= len;                                // :258
-            uint32_t hop = 1;
-            const uint32_t l1 = row_len8_next1(w);
-            if (l1 != kLen8Long && t >= l1 && j + 1 < T.r - 1) {
-                t -= l1;
-                hop = 2;
-                const uint32_t l2 = row_len8_next2(w);
-                if (l2 != kLen8Long && t >= l2 && j + 2 < T.r - 1) {
-                    t -= l2;
-                    hop = 3;
-                }
-            }
-            j += hop;
+            ++j;
             w = T.rows[j];
         }
         i = j;
