@@ -8,29 +8,6 @@
 
 namespace colbwt {
 
-// Read bytes: 64 bytes of the lane's read (one 64-byte-aligned block of `bases`,
-// 4 x uint4 from one HBM line) are staged in LDS, dword-major ([16][block] so
-// consecutive lanes hit consecutive banks); each step reads its byte from there.
-struct ReadWindow {
-    __device__ __forceinline__ void refill(uint32_t (*s_rd)[kQueryBlock], const uint8_t *bases, uint64_t g) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(bases + (g & ~(uint64_t)63));
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = src[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s_rd[4 * q + 0][threadIdx.x] = v[q].x;
-            s_rd[4 * q + 1][threadIdx.x] = v[q].y;
-            s_rd[4 * q + 2][threadIdx.x] = v[q].z;
-            s_rd[4 * q + 3][threadIdx.x] = v[q].w;
-        }
-    }
-    __device__ __forceinline__ uint32_t get(uint32_t (*s_rd)[kQueryBlock], uint64_t g) {
-        const uint32_t b = (uint32_t)g & 63u;
-        return (s_rd[b >> 2][threadIdx.x] >> (8 * (b & 3u))) & 0xFFu;
-    }
-};
-
 // Output collector: kFlush = 16 bases per flush, flush boundaries at global
 // element indices that are multiples of 16, so a full flush is aligned vector
 // stores covering whole 32-byte sectors; partial groups (read ends) go out in

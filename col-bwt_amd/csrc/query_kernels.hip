@@ -19,8 +19,9 @@
 //     distinct lines a step touches: rows are 16-byte aligned (8 per line), the
 //     threshold decision is pre-resolved into 2-bit hints inside the row, and
 //     a mismatch runs only the scan whose result it will use;
-//   * read bytes: each lane stages 64 bytes of its read in LDS per refill
-//     (4 x 16 B from one line) and picks one byte per step from there;
+//   * read bytes: each lane stages 64 bytes of its read in LDS per refill and picks one
+//     byte per step from there; the window slides and is refilled for the whole wave at
+//     once (lane_io.h SlidingWindow);
 //   * PML (u16) and col id (u8) are collected for 16 bases in registers and
 //     leave as 32-byte and 16-byte aligned stores (whole 32-byte sectors).
 #include <hip/hip_runtime.h>
@@ -136,12 +137,13 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
     uint64_t o = row_len(T, i, w) - 1;
     uint32_t L = 0;
 
-    ReadWindow win;
+    SlidingWindow win;          // refilled for the whole wave when any lane runs out (lane_io.h)
     OutAcc<PmlT> acc;
-    win.refill(s_rd, bases, off + m - 1);
+    win.init(off + m - 1);
 
     for (uint64_t k = m; k-- > 0;) {                 // col_bwt.hpp:510, i = m-1-k
         const uint64_t g = off + k;
+        if (__any(win.avail(g) < 1)) win.refill(s_rd, bases, g);
         const uint32_t c = win.get(s_rd, g);         // :512 pattern[m-i-1], raw byte
         const uint32_t col_id = row_cid(w);          // :513 before any re-orientation
         if (row_char(w) == c) {                      // :516
@@ -158,7 +160,6 @@ void pml_query_kernel(DevTable T, const uint8_t *__restrict__ bases,
             if ((g & (kFlush - 1)) == 0) acc.flush(pml, cid, g);
         }
         if (k == 0) break;  // the reference's last LF (col_bwt.hpp:527) has no observable effect
-        if ((g & 63) == 0) win.refill(s_rd, bases, g - 1);
 
         // LF_table::LF (LF_table.hpp:251-262).  The row knows where its image leaves the landing
         // row and the row after it (cut_a, len_b), so the first steps of the fast-forward
