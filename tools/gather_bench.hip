@@ -13,7 +13,9 @@
 //   mode 4: 16 B in two adjacent 128 B lines
 //   mode 5..8: as mode 0 with cache-policy bits: nt | sc1 | sc0 sc1 | sc0 sc1 nt
 //   mode 9: all 8 x 16 B of one aligned 128 B line (the fat-row shape)
-//   alloc 0: hipMalloc, 1: hipDeviceMallocUncached, 2: hipDeviceMallocFinegrained
+//   mode 10: 2 x 16 B = one aligned 32 B row (the three-step row shape)
+//   alloc 0: hipMalloc, 1: hipDeviceMallocUncached, 2: hipDeviceMallocFinegrained,
+//         3: hipDeviceMallocContiguous (physically contiguous: larger TLB fragments?)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,11 +52,13 @@ __global__ __launch_bounds__(256) void chase(const uint4 *__restrict__ t, uint64
     for (uint32_t s = 0; s < steps; ++s) {
         if (MODE == 2) j &= ~(uint64_t)3;
         if (MODE == 3 || MODE == 9) j &= ~(uint64_t)7;
+        if (MODE == 10) j &= ~(uint64_t)1;
         if (MODE == 4) { j &= ~(uint64_t)7; if (j + 16 > rows) j = 0; }
         uint4 w = load_policy<MODE>(t + j);
         if (MODE == 1) { uint4 w2 = t[j + 1 < rows ? j + 1 : j]; acc += w2.z; }
         if (MODE == 2) { uint4 a = t[j + 1], b = t[j + 2], c = t[j + 3]; acc += a.z + b.z + c.z; }
         if (MODE == 3) { uint4 a = t[j + 4]; acc += a.z; }
+        if (MODE == 10) { uint4 a = t[j + 1]; acc += a.z; }
         if (MODE == 9) {
             uint4 a = t[j + 1], b = t[j + 2], c = t[j + 3], d = t[j + 4], e = t[j + 5], f = t[j + 6], h = t[j + 7];
             acc += a.z + b.z + c.z + d.z + e.z + f.z + h.z;
@@ -82,6 +86,7 @@ int main(int argc, char **argv) {
     uint4 *t; uint32_t *out;
     if (alloc == 1) CK(hipExtMallocWithFlags((void **)&t, rows * 16, hipDeviceMallocUncached));
     else if (alloc == 2) CK(hipExtMallocWithFlags((void **)&t, rows * 16, hipDeviceMallocFinegrained));
+    else if (alloc == 3) CK(hipExtMallocWithFlags((void **)&t, rows * 16, hipDeviceMallocContiguous));
     else CK(hipMalloc(&t, rows * 16));
     CK(hipMalloc(&out, lanes * 4 + 1024));
     fill<<<4096, 256>>>(t, rows);
@@ -100,6 +105,7 @@ int main(int argc, char **argv) {
             case 6: run<6>(blocks, t, rows, steps, out); break;
             case 7: run<7>(blocks, t, rows, steps, out); break;
             case 9: run<9>(blocks, t, rows, steps, out); break;
+            case 10: run<10>(blocks, t, rows, steps, out); break;
             default: run<8>(blocks, t, rows, steps, out); break;
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
