@@ -427,16 +427,29 @@ def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
     g_pml = torch.full((world, words * 32), -1, dtype=torch.int16, device=dev)
     pkg.read_end_mask_device(d_off.data_ptr(), n_reads, d_end.data_ptr(), stream.cuda_stream)
 
-    class Work:
+    nccl_stream = torch.cuda.Stream(device=dev)
+
+    class Work:                                    # like ProcessGroupNCCL's: wait() orders the CURRENT stream
+        def __init__(self, ev):
+            self.ev = ev
+
         def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
             return True
 
-    class FakeDist:                                # rank 0 of `world`: every rank sends what this GPU holds
+    class FakeDist:
+        """rank 0 of `world`: every rank sends what this GPU holds.  The transfer runs on its own
+        stream, behind whatever the calling stream had queued when gather() was called -- the
+        stream semantics of an RCCL collective with async_op=True."""
         @staticmethod
         def gather(src, glist, dst=0, async_op=False):
-            for g in glist:
-                g.copy_(src, non_blocking=True)
-            return Work()
+            nccl_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(nccl_stream):
+                for g in glist:
+                    g.copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(nccl_stream)
+            return Work(ev)
 
     def query_chunk(lo, hi):
         tbl.query_device(d_bases.data_ptr(), d_off.data_ptr() + 8 * lo, hi - lo, (hi - lo) * m,
