@@ -122,24 +122,34 @@ struct D2HSegment {
     size_t bytes;
 };
 
+// Both pinned staging buffers of the handle, or neither: a failed allocation is "not staged"
+// (the caller takes the plain copy), never a half-initialised pair.
+bool ensure_stage(colbwt_index *idx) {
+    if (idx->stage[0] && idx->stage[1]) return true;
+    for (int b = 0; b < 2; ++b)
+        if (hipHostMalloc(&idx->stage[b], kStageBytes, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            idx->stage[b] = nullptr;
+            if (idx->stage[0]) (void)hipHostFree(idx->stage[0]);
+            idx->stage[0] = nullptr;
+            return false;
+        }
+    idx->stage_bytes = kStageBytes;
+    return true;
+}
+
 // Device -> pageable host memory through the handle's two pinned buffers: the DMA of chunk
 // k runs while host threads copy chunk k-1 out of its buffer.  Returns hipSuccess or the
 // first HIP error; the stream is idle afterwards.
 hipError_t staged_d2h(colbwt_index *idx, const D2HSegment *seg, int n_seg, hipStream_t stream) {
     hipError_t e = hipSuccess;
-    if (!idx->stage[0]) {
-        for (int b = 0; b < 2; ++b) {
-            e = hipHostMalloc(&idx->stage[b], kStageBytes, 0);
-            if (e != hipSuccess) {
-                idx->stage[b] = nullptr;
-                return e;
-            }
-        }
-        idx->stage_bytes = kStageBytes;
-    }
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (auto &x : ev)
-        if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&x, hipEventDisableTiming)) != hipSuccess) {
+            for (auto &y : ev)
+                if (y) (void)hipEventDestroy(y);
+            return e;
+        }
     struct Piece {
         uint8_t *dst;
         size_t n;
@@ -244,7 +254,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         // small batches are copied directly
         std::unique_lock<std::mutex> stage_lock(idx->stage_mu, std::defer_lock);
         const bool staged = n_bases * (sizeof(PmlT) + 1) >= kStageMinTotal && is_pageable(pml) && is_pageable(cid) &&
-                            stage_lock.try_lock();
+                            stage_lock.try_lock() && ensure_stage(idx);
         if (staged) {
             const D2HSegment seg[2] = {{(uint8_t *)pml, (const uint8_t *)d_pml, n_bases * sizeof(PmlT)},
                                        {cid, d_cid, n_bases}};
@@ -650,7 +660,10 @@ int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 64, stream));
-    launch_synth_reads(idx->ix.table(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
+    if (idx->ix.layout() >= 2)   // the one-step tables are gone once the K-step rows exist
+        launch_sk_synth_reads(idx->ix.table_k(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
+    else
+        launch_synth_reads(idx->ix.table(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
     API_HIP(hipGetLastError());
     rc = COLBWT_OK;
 done:

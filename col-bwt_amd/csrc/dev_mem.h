@@ -1,0 +1,109 @@
+// dev_mem.h -- device allocations of the index builder: every table and every temporary of
+// Index::load / build_sk goes through dev_alloc / dev_free, so that
+//   * a failed build frees what it had allocated (DevPtr is RAII; the failure paths of the
+//     K-step refinement used to leak their temporaries -- exactly where the AUTO layout
+//     fallback needs the HBM back), and
+//   * an index can be held to an HBM budget: COLBWT_HBM_BUDGET_MB (environment) bounds the bytes
+//     ONE open may hold at any moment, temporaries included; an allocation beyond it fails like
+//     a real hipErrorOutOfMemory.  Used to keep room for read batches next to a large index, and
+//     by the tests to force the fallback without filling 288 GB.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+namespace colbwt {
+
+struct DevBudget {
+    uint64_t limit = ~0ull;   // bytes
+    uint64_t used = 0;
+    uint64_t peak = 0;
+};
+
+// the budget of the open that is running on this thread (nullptr: unlimited, untracked)
+inline DevBudget *&current_budget() {
+    static thread_local DevBudget *b = nullptr;
+    return b;
+}
+
+inline uint64_t env_budget_bytes() {
+    const char *e = getenv("COLBWT_HBM_BUDGET_MB");
+    if (!e || !*e) return ~0ull;
+    char *end = nullptr;
+    const double mb = strtod(e, &end);   // fractions allowed ("0.5")
+    if (end == e || !(mb > 0)) return ~0ull;
+    return (uint64_t)(mb * 1048576.0);
+}
+
+inline hipError_t dev_alloc(void **p, uint64_t bytes) {
+    *p = nullptr;
+    DevBudget *b = current_budget();
+    if (b && (bytes > b->limit || b->used > b->limit - bytes)) return hipErrorOutOfMemory;
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        (void)hipGetLastError();   // the caller reports `e`; do not leave it for a later hipGetLastError
+        return e;
+    }
+    if (b) {
+        b->used += bytes;
+        if (b->used > b->peak) b->peak = b->used;
+    }
+    return hipSuccess;
+}
+
+inline void dev_free(void *p, uint64_t bytes) {
+    if (!p) return;
+    (void)hipFree(p);
+    DevBudget *b = current_budget();
+    if (b) b->used = b->used > bytes ? b->used - bytes : 0;
+}
+
+// Owner of one device allocation.
+class DevPtr {
+public:
+    DevPtr() = default;
+    DevPtr(const DevPtr &) = delete;
+    DevPtr &operator=(const DevPtr &) = delete;
+    DevPtr(DevPtr &&o) noexcept : p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+    DevPtr &operator=(DevPtr &&o) noexcept {
+        if (this != &o) {
+            reset();
+            p_ = o.p_;
+            bytes_ = o.bytes_;
+            o.p_ = nullptr;
+            o.bytes_ = 0;
+        }
+        return *this;
+    }
+    ~DevPtr() { reset(); }
+    hipError_t alloc(uint64_t bytes) {
+        reset();
+        const hipError_t e = dev_alloc(&p_, bytes);
+        if (e == hipSuccess) bytes_ = bytes;
+        return e;
+    }
+    void reset() {
+        dev_free(p_, bytes_);
+        p_ = nullptr;
+        bytes_ = 0;
+    }
+    // hands the allocation over to a longer-lived owner (which frees it with dev_free)
+    void *release(uint64_t *bytes = nullptr) {
+        void *p = p_;
+        if (bytes) *bytes = bytes_;
+        p_ = nullptr;
+        bytes_ = 0;
+        return p;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p_); }
+    void *get() const { return p_; }
+    uint64_t bytes() const { return bytes_; }
+
+private:
+    void *p_ = nullptr;
+    uint64_t bytes_ = 0;
+};
+
+}  // namespace colbwt

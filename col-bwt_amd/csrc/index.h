@@ -6,6 +6,7 @@
 
 #include <string>
 
+#include "dev_mem.h"
 #include "device_layout.h"
 #include "query_kernels.h"
 #include "sk_layout.h"
@@ -38,18 +39,20 @@ public:
     uint64_t n() const { return tbl_.n; }
     uint64_t r() const { return tbl_.r; }
     uint32_t sigma() const { return tbl_.sigma; }
-    uint64_t device_bytes() const { return device_bytes_; }
+    uint64_t device_bytes() const;                                  // HBM held now
+    uint64_t peak_device_bytes() const { return peak_device_bytes_; }  // ... and at most while loading
 
 private:
     void release();
+    void release_one_step();
     DevTable tbl_{};
     SKTable tblk_{};
     SKBuffers bufk_;
     int layout_ = 1;
     uint64_t bwt_r_ = 0;
     int device_ = -1;
-    uint64_t device_bytes_ = 0;
-    void *d_rows_ = nullptr, *d_idx_ = nullptr, *d_thr_ = nullptr, *d_next_ = nullptr, *d_prev_ = nullptr, *d_cmap_ = nullptr;
+    uint64_t peak_device_bytes_ = 0;
+    DevPtr d_rows_, d_idx_, d_thr_, d_next_, d_prev_, d_cmap_;
 };
 
 // Selects `device` after checking that a usable gfx950-class HIP device exists.

@@ -12,16 +12,21 @@
 #include <vector>
 
 #include "../../include/colbwt.h"
+#include "dev_mem.h"
 #include "jump_tables.h"
 #include "query_kernels.h"
 
 namespace colbwt {
 
+// A failed HIP call ends the load with the matching C-ABI code.  Every allocation is owned by a
+// DevPtr (member tables, local temporaries), so a failed load leaves nothing behind.
 #define HIP_TRY(expr)                                                                  \
     do {                                                                               \
         hipError_t e_ = (expr);                                                        \
         if (e_ != hipSuccess) {                                                        \
             err = std::string(#expr) + ": " + hipGetErrorString(e_);                   \
+            (void)hipGetLastError();                                                   \
+            release();                                                                 \
             return e_ == hipErrorOutOfMemory ? COLBWT_ERR_NOMEM : COLBWT_ERR_HIP;      \
         }                                                                              \
     } while (0)
@@ -47,15 +52,33 @@ int select_device(int device, std::string &err) {
 
 Index::~Index() { release(); }
 
+void Index::release_one_step() {
+    for (DevPtr *p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_}) p->reset();
+    tbl_.rows = nullptr;
+    tbl_.idx = tbl_.thr = nullptr;
+    tbl_.next_tbl = tbl_.prev_tbl = nullptr;
+}
+
 void Index::release() {
     if (device_ >= 0) (void)hipSetDevice(device_);
-    for (void **p : {&d_rows_, &d_idx_, &d_thr_, &d_next_, &d_prev_, &d_cmap_}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
+    release_one_step();
+    d_cmap_.reset();
     bufk_.release();
-    device_bytes_ = 0;
 }
+
+uint64_t Index::device_bytes() const {
+    return d_rows_.bytes() + d_idx_.bytes() + d_thr_.bytes() + d_next_.bytes() + d_prev_.bytes() + d_cmap_.bytes() +
+           bufk_.bytes();
+}
+
+namespace {
+// the budget of the open running on this thread (dev_mem.h), dropped when the load returns
+struct BudgetScope {
+    DevBudget b;
+    BudgetScope() { b.limit = env_budget_bytes(); current_budget() = &b; }
+    ~BudgetScope() { current_budget() = nullptr; }
+};
+}  // namespace
 
 static inline uint64_t rd_u64(const uint8_t *p) {
     uint64_t v;
@@ -89,6 +112,8 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     int rc = select_device(device, err);
     if (rc != COLBWT_OK) return rc;
     release();
+    (void)hipGetLastError();   // a stale error of an earlier attempt must not fail this one
+    BudgetScope budget;
     device_ = device;
     bwt_r_ = bwt_r;
 
@@ -97,41 +122,35 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
 
     // r rows + the sentinel, padded to whole 128-byte lines (8 rows) so line-wide loads stay in bounds
     const uint64_t rows_alloc = ((r + 1 + 7) & ~7ull) * sizeof(uint4);
-    HIP_TRY(hipMalloc(&d_rows_, rows_alloc));
-    HIP_TRY(hipMemset(d_rows_, 0, rows_alloc));
-    HIP_TRY(hipMalloc(&d_idx_, (r + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&d_thr_, r * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&d_cmap_, 256));
-    device_bytes_ = rows_alloc + (2 * r + 1) * sizeof(uint64_t) + 256;
+    HIP_TRY(d_rows_.alloc(rows_alloc));
+    HIP_TRY(hipMemset(d_rows_.get(), 0, rows_alloc));
+    HIP_TRY(d_idx_.alloc((r + 1) * sizeof(uint64_t)));
+    HIP_TRY(d_thr_.alloc(r * sizeof(uint64_t)));
+    HIP_TRY(d_cmap_.alloc(256));
 
     // ---- upload packed rows chunk by chunk and re-lay them out on the device
-    RelayoutReport *d_report = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_report, sizeof(RelayoutReport)));
     RelayoutReport h_report{};
     h_report.first_bad = kNone;
-    HIP_TRY(hipMemcpy(d_report, &h_report, sizeof(h_report), hipMemcpyHostToDevice));
-
-    const uint64_t chunk_rows = 16ull << 20;  // 288 MiB of packed rows per staging pass
-    const uint64_t stage_rows = std::min<uint64_t>(chunk_rows, r);
-    uint8_t *d_raw = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_raw, (stage_rows + 3) * kRowBytesDisk + 64));
-    for (uint64_t row0 = 0; row0 < r; row0 += chunk_rows) {
-        const uint64_t count = std::min<uint64_t>(chunk_rows, r - row0);
-        const uint64_t with_next = std::min<uint64_t>(count + 3, r - row0);  // following rows' idx for run lengths
-        hipError_t e = hipMemcpy(d_raw, rows_disk + row0 * kRowBytesDisk, with_next * kRowBytesDisk,
-                                 hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(d_raw);
-            (void)hipFree(d_report);
-            err = std::string("hipMemcpy(rows): ") + hipGetErrorString(e);
-            return COLBWT_ERR_HIP;
+    {
+        DevPtr report_buf, raw_buf;
+        HIP_TRY(report_buf.alloc(sizeof(RelayoutReport)));
+        RelayoutReport *d_report = report_buf.as<RelayoutReport>();
+        HIP_TRY(hipMemcpy(d_report, &h_report, sizeof(h_report), hipMemcpyHostToDevice));
+        const uint64_t chunk_rows = 16ull << 20;  // 288 MiB of packed rows per staging pass
+        const uint64_t stage_rows = std::min<uint64_t>(chunk_rows, r);
+        HIP_TRY(raw_buf.alloc((stage_rows + 3) * kRowBytesDisk + 64));
+        uint8_t *d_raw = raw_buf.as<uint8_t>();
+        for (uint64_t row0 = 0; row0 < r; row0 += chunk_rows) {
+            const uint64_t count = std::min<uint64_t>(chunk_rows, r - row0);
+            const uint64_t with_next = std::min<uint64_t>(count + 3, r - row0);  // following rows' idx for run lengths
+            HIP_TRY(hipMemcpy(d_raw, rows_disk + row0 * kRowBytesDisk, with_next * kRowBytesDisk, hipMemcpyHostToDevice));
+            launch_relayout(d_raw, row0, count, r, n, d_rows_.as<uint4>(), d_idx_.as<uint64_t>(), d_thr_.as<uint64_t>(),
+                            d_report, 0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(0));
         }
-        launch_relayout(d_raw, row0, count, r, n, (uint4 *)d_rows_, (uint64_t *)d_idx_, (uint64_t *)d_thr_, d_report, 0);
-        HIP_TRY(hipStreamSynchronize(0));
+        HIP_TRY(hipMemcpy(&h_report, d_report, sizeof(h_report), hipMemcpyDeviceToHost));
     }
-    (void)hipFree(d_raw);
-    HIP_TRY(hipMemcpy(&h_report, d_report, sizeof(h_report), hipMemcpyDeviceToHost));
-    (void)hipFree(d_report);
     if (h_report.flags) {
         err = "corrupt .col_pml near row " + std::to_string(h_report.first_bad) + ":";
         if (h_report.flags & 1u) err += " idx not strictly increasing;";
@@ -162,33 +181,33 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         release();
         return COLBWT_ERR_FORMAT;
     }
-    HIP_TRY(hipMemcpy(d_cmap_, cmap, 256, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_cmap_.get(), cmap, 256, hipMemcpyHostToDevice));
 
     // ---- jump tables bounding succ_char / pred_char (LF_table.hpp:271-298)
     const uint64_t tbl_entries = (uint64_t)nblk * sigma;
-    HIP_TRY(hipMalloc(&d_next_, std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_prev_, std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
-    device_bytes_ += 2 * std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t);
+    HIP_TRY(d_next_.alloc(std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
+    HIP_TRY(d_prev_.alloc(std::max<uint64_t>(tbl_entries, 1) * sizeof(uint32_t)));
     {
-        launch_block_first_last((const uint4 *)d_rows_, (uint32_t)r, nblk, sigma, (const uint8_t *)d_cmap_,
-                                (uint32_t *)d_next_, (uint32_t *)d_prev_, 0);
+        launch_block_first_last(d_rows_.as<uint4>(), (uint32_t)r, nblk, sigma, d_cmap_.as<uint8_t>(), d_next_.as<uint32_t>(),
+                                d_prev_.as<uint32_t>(), 0);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(0));
         std::vector<uint32_t> first(tbl_entries), last(tbl_entries);
-        HIP_TRY(hipMemcpy(first.data(), d_next_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(last.data(), d_prev_, tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(first.data(), d_next_.get(), tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(last.data(), d_prev_.get(), tbl_entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
         // next[b][c] = first run >= b*B holding c ; prev[b][c] = last run < b*B holding c
         std::vector<uint32_t> next, prev;
         finish_jump_tables(first, last, nblk, sigma, next, prev);
-        HIP_TRY(hipMemcpy(d_next_, next.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_prev_, prev.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_next_.get(), next.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_prev_.get(), prev.data(), tbl_entries * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
 
-    tbl_.rows = (const uint4 *)d_rows_;
-    tbl_.idx = (const uint64_t *)d_idx_;
-    tbl_.thr = (const uint64_t *)d_thr_;
-    tbl_.next_tbl = (const uint32_t *)d_next_;
-    tbl_.prev_tbl = (const uint32_t *)d_prev_;
-    tbl_.cmap = (const uint8_t *)d_cmap_;
+    tbl_.rows = d_rows_.as<uint4>();
+    tbl_.idx = d_idx_.as<uint64_t>();
+    tbl_.thr = d_thr_.as<uint64_t>();
+    tbl_.next_tbl = d_next_.as<uint32_t>();
+    tbl_.prev_tbl = d_prev_.as<uint32_t>();
+    tbl_.cmap = d_cmap_.as<uint8_t>();
     tbl_.n = n;
     tbl_.r = (uint32_t)r;
     tbl_.sigma = sigma;
@@ -200,22 +219,25 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         HintChars hc{};
         for (uint32_t c = 0; c < 256; ++c)
             if (cmap[c] != kAbsent && cmap[c] < 8) hc.c[cmap[c]] = (uint8_t)c;
-        launch_hints(tbl_, (uint4 *)d_rows_, hc, 0);
+        launch_hints(tbl_, d_rows_.as<uint4>(), hc, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(0));
         tbl_.use_hints = 1;
 
-        // ---- optional K-step layout on top (sk_layout.h)
+        // ---- optional K-step layout on top (sk_layout.h).  The one-step tables are only the
+        // source of the refinement: they are freed as soon as the last pass that reads them is
+        // done (before level 3 is allocated), and the K-step index keeps just cmap.
         layout_ = 1;
         if (layout == 2 || layout == 3) {
-            if (!build_sk(tbl_, hc, layout, tblk_, bufk_, err)) {
+            rc = build_sk(tbl_, hc, layout, tblk_, bufk_, err, [this] { release_one_step(); });
+            if (rc != COLBWT_OK) {
                 release();
-                return COLBWT_ERR_NOMEM;
+                return rc;
             }
-            device_bytes_ += bufk_.bytes;
             layout_ = layout;
         }
     }
+    peak_device_bytes_ = budget.b.peak;
     return COLBWT_OK;
 }
 

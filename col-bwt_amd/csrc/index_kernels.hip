@@ -7,6 +7,7 @@
 #include "device_layout.h"
 #include "lf_device.h"
 #include "query_kernels.h"
+#include "read_sampler.h"
 
 namespace colbwt {
 
@@ -58,10 +59,8 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         const uint32_t offset = (uint32_t)lds_le(p + 10, 2);
         const uint32_t cid = p[12];
         const uint64_t threshold = lds_le(p + 13, 5);
-        // idx of rows i+1 .. i+3 (n past the end): lengths of this row and of the next two
+        // idx of row i+1 (n past the end): the length of this row
         const uint64_t next_idx = (i + 1 < r) ? lds_le(p + kRowBytesDisk + 1, 5) : n;
-        const uint64_t next2_idx = (i + 2 < r) ? lds_le(p + 2 * kRowBytesDisk + 1, 5) : n;
-        const uint64_t next3_idx = (i + 3 < r) ? lds_le(p + 3 * kRowBytesDisk + 1, 5) : n;
 
         uint32_t flags = 0;
         if (next_idx <= idx) flags |= (i + 1 < r) ? 1u : 4u;  // not strictly increasing / last idx >= n
@@ -73,8 +72,6 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
         }
         const uint64_t len = next_idx - idx;
         const uint32_t len16 = len < kLenLong ? (uint32_t)len : kLenLong;
-        (void)next2_idx;
-        (void)next3_idx;
         rows[i] = make_uint4(interval, offset | (len16 << 16), 0xFFFFFFFFu,   // cuts / distances: hint_kernel
                              (ch << 8) | (cid << 16) | (kHintAllCompare << 24));
         idx_out[i] = idx;
@@ -185,17 +182,20 @@ __global__ __launch_bounds__(256) void hint_kernel(DevTable T, uint4 *rows_rw, H
     rows_rw[i].w = (w.w & 0x00FFFFFFu) | (hints << 24);
 }
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
+struct OneStepView {
+    DevTable T;
+    __device__ __forceinline__ uint64_t n() const { return T.n; }
+    __device__ __forceinline__ uint32_t rows() const { return T.r; }
+    __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
+    __device__ __forceinline__ uint4 load(uint32_t j) const { return T.rows[j]; }
+    __device__ __forceinline__ uint32_t ch(const uint4 &w) const { return row_char(w); }
+    __device__ __forceinline__ uint32_t lf_row(const uint4 &w) const { return row_interval(w); }
+    __device__ __forceinline__ uint32_t lf_off(const uint4 &w) const { return row_offset(w); }
+    __device__ __forceinline__ uint64_t len(uint32_t j, const uint4 &) const { return T.idx[(uint64_t)j + 1] - T.idx[j]; }
+};
 
-
-// Synthetic reads by backward walk: read[m-1-k] = char at
-// LF^k(p0).  Generator only -- results are inputs, never checked outputs.
-__global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n_reads, uint32_t m,
+// Synthetic reads by backward walk (read_sampler.h).
+__global__ __launch_bounds__(256) void synth_reads_kernel(OneStepView V, uint64_t n_reads, uint32_t m,
                                                           uint32_t sub_permille, uint64_t seed,
                                                           uint8_t *__restrict__ bases,
                                                           uint64_t *__restrict__ read_off) {
@@ -203,43 +203,7 @@ __global__ __launch_bounds__(256) void synth_reads_kernel(DevTable T, uint64_t n
     if (rd > n_reads) return;
     read_off[rd] = rd * m;
     if (rd == n_reads) return;
-    uint64_t st = splitmix64(seed ^ (rd * 0xD1342543DE82EF95ull));
-    const uint64_t p0 = st % T.n;
-    // largest i with idx[i] <= p0
-    uint64_t lo = 0, hi = T.r;  // idx[lo] <= p0 < idx[hi] (sentinel idx[r] = n)
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (T.idx[mid] <= p0) lo = mid; else hi = mid;
-    }
-    uint32_t i = (uint32_t)lo;
-    uint4 w = T.rows[i];
-    uint64_t o = p0 - T.idx[i];
-    uint8_t *out = bases + rd * m;
-    const char acgt[4] = {'A', 'C', 'G', 'T'};
-    for (uint32_t k = 0; k < m; ++k) {
-        uint32_t ch = (w.w >> 8) & 0xFFu;
-        if (ch <= 1) ch = 'A';
-        st = splitmix64(st);
-        if ((uint32_t)(st % 1000) < sub_permille) {
-            uint32_t cur = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
-            uint32_t pick = (uint32_t)((st >> 32) % 3);
-            ch = cur < 4 ? acgt[(cur + 1 + pick) & 3] : acgt[(st >> 40) & 3];
-        }
-        out[m - 1 - k] = (uint8_t)ch;
-        uint32_t j = w.x;
-        uint64_t t = (uint64_t)(w.y & 0xFFFFu) + o;
-        w = T.rows[j];
-        for (;;) {
-            const uint64_t len = T.idx[(uint64_t)j + 1] - T.idx[j];
-            if (t < len || j >= T.r - 1) break;
-            t -= len;
-            ++j;
-            w = T.rows[j];
-        }
-        i = j;
-        o = t;
-    }
-    (void)i;
+    sample_read(V, rd, m, sub_permille, seed, bases + rd * m);
 }
 
 }  // namespace
@@ -267,7 +231,7 @@ void launch_hints(const DevTable &T, uint4 *d_rows_rw, const HintChars &chars, h
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille, uint64_t seed,
                         uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream) {
     const uint64_t blocks = (n_reads + 1 + 255) / 256;
-    hipLaunchKernelGGL(synth_reads_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, T, n_reads, read_len,
+    hipLaunchKernelGGL(synth_reads_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, OneStepView{T}, n_reads, read_len,
                        sub_permille, seed, d_bases, d_read_off);
 }
 

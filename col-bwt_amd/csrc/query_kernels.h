@@ -16,8 +16,11 @@ void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t 
                       hipStream_t stream);
 
 }  // namespace colbwt
+#include <functional>
 #include <string>
 
+#include "dev_mem.h"
+#include "fat_layout.h"
 #include "sk_layout.h"
 namespace colbwt {
 
@@ -55,16 +58,39 @@ void launch_pml_unpack(const uint32_t *d_flag, const uint32_t *d_last, uint64_t 
 
 // Device allocations of one K-step table.
 struct SKBuffers {
-    void *lines = nullptr, *idx = nullptr, *thr = nullptr, *next = nullptr, *prev = nullptr;
-    uint64_t bytes = 0;
+    DevPtr lines, idx, thr, next, prev;
+    uint64_t bytes() const;
     void release();
 };
-// K-step layout (steps = 2 or 3) from the one-step tables (sk_build.hip); false + err when it
-// cannot be built (more than 2^32-2 rows, out of memory).
-bool build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err);
+// K-step layout (steps = 2 or 3) from the one-step tables (sk_build.hip).  COLBWT_OK, or
+// COLBWT_ERR_NOMEM when it cannot be built for lack of room (HBM, or more than 2^32-2 refined
+// rows -- a shallower layout may fit), or COLBWT_ERR_HIP; `err` says what failed and nothing
+// stays allocated.  `source_done` is called once the one-step tables are no longer read.
+int build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err,
+             const std::function<void()> &source_done);
 
-// Backward-walk read sampler (synthetic benchmark input).
+// Device allocations of a line-row table (fat_layout.h).
+struct FatBuffers {
+    DevPtr lines, chr, idx, thr, next, prev;
+    uint64_t bytes() const;
+    void release();
+};
+// Line rows with `steps` own steps and `slot_steps` steps per mismatch slot (fat_build.hip); same
+// contract as build_sk.  fat_shape_supported: the shapes compiled in.
+bool fat_shape_supported(int steps, int slot_steps);
+int build_fat(const DevTable &T, const HintChars &chars, int steps, int slot_steps, FatTable &out, FatBuffers &buf,
+              std::string &err, const std::function<void()> &source_done);
+// The query over line rows (fat_query.hip).
+void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+                      void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
+void launch_fat_synth_reads(const FatTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
+                            uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);
+
+// Backward-walk read sampler (synthetic benchmark input); the same reads come
+// out of every layout (a read is a function of its start position in the BWT).
 void launch_synth_reads(const DevTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                         uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);
+void launch_sk_synth_reads(const SKTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
+                           uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);
 
 }  // namespace colbwt

@@ -13,64 +13,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
+#include "../../include/colbwt.h"
+#include "dev_mem.h"
 #include "device_layout.h"
 #include "jump_tables.h"
 #include "lf_device.h"
 #include "query_kernels.h"
+#include "read_sampler.h"
+#include "refine.h"
 #include "sk_layout.h"
 
 namespace colbwt {
 
 namespace {
-
-// ---- source views: what a refinement pass needs from the level below ------
-struct SrcL1 {  // the one-step table
-    DevTable T;
-    HintChars chars;
-    static constexpr int kSteps = 1;
-    // Positions strictly inside row i where a mismatch on one of the hinted characters
-    // changes sides: the threshold of that character's next run (col_bwt.hpp:552-560).
-    // The first refinement cuts there too, so that no refined row contains a threshold
-    // and every hint is decided -- in a real index the threshold of a run lies between
-    // the previous run of its character and its head, i.e. inside one of the rows in
-    // between, and the query would otherwise fall back to scans + position compares.
-    __device__ __forceinline__ uint32_t cuts(uint32_t i, uint64_t (&cut)[kHintSlots]) const {
-        const uint4 w = T.rows[i];
-        const uint32_t aidx = T.cmap[row_char(w)];
-        const uint32_t top = T.sigma < kHintMaxSigma ? T.sigma : kHintMaxSigma;
-        uint32_t nc = 0;
-        for (uint32_t cidx = 0; cidx < top; ++cidx) {
-            const uint32_t slot = hint_slot(cidx, aidx);
-            if (cidx == aidx || slot >= kHintSlots) continue;
-            if (((row_hints(w) >> (2 * slot)) & 3u) != kHintCompare) continue;
-            uint4 t;
-            const uint32_t s = succ_char(T, i, chars.c[cidx], cidx, t);
-            if (s == kNone) continue;                  // thr = n: never inside a row
-            const uint64_t thr = T.thr[s];
-            uint32_t q = nc++;                         // insertion sort, ascending
-            while (q > 0 && cut[q - 1] > thr) { cut[q] = cut[q - 1]; --q; }
-            cut[q] = thr;
-        }
-        return nc;
-    }
-    __device__ __forceinline__ uint32_t rows() const { return T.r; }
-    __device__ __forceinline__ uint64_t n() const { return T.n; }
-    __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
-    __device__ __forceinline__ uint64_t len(uint32_t j) const { return T.idx[(uint64_t)j + 1] - T.idx[j]; }
-    __device__ __forceinline__ uint64_t thr(uint32_t j) const { return T.thr[j]; }
-    // (row, offset) of LF^s(first position of row j); may still need the fast-forward
-    __device__ __forceinline__ void lf(uint32_t j, int, uint32_t &dj, uint64_t &dt) const {
-        const uint4 w = T.rows[j];
-        dj = row_interval(w);
-        dt = row_offset(w);
-    }
-    // character / col id met after a-1 LF steps from any position of row j (a = 1 only)
-    __device__ __forceinline__ uint32_t ch_at(uint32_t j, int) const { return row_char(T.rows[j]); }
-    __device__ __forceinline__ uint32_t cid_at(uint32_t j, int) const { return row_cid(T.rows[j]); }
-};
 
 template <int KS>
 struct SrcSK {  // a K-step table as the source of the next level
@@ -100,99 +59,6 @@ struct SrcSK {  // a K-step table as the source of the next level
         return sk_cid_at<KS, 2>(w);
     }
 };
-
-// Fast-forward (LF_table.hpp:256-259) of (j, t) over the source rows.
-template <class Src>
-__device__ __forceinline__ void src_ff(const Src &S, uint32_t &j, uint64_t &t) {
-    uint64_t lenj = S.len(j);
-    while (t >= lenj && j < S.rows() - 1) {
-        t -= lenj;
-        ++j;
-        lenj = S.len(j);
-    }
-}
-
-// Walks the LF image of source row i piece by piece: f(piece_start, piece_len, j, t)
-// with (j, t) = source row / offset the piece's first position maps to.
-template <class Src, typename F>
-__device__ __forceinline__ void for_each_piece(const Src &S, uint32_t i, F f) {
-    uint64_t rem = S.len(i);
-    uint64_t b = S.idx(i);
-    uint64_t cut[kHintSlots];
-    const uint32_t nc = S.cuts(i, cut);
-    uint32_t ci = 0;
-    uint32_t j;
-    uint64_t t;
-    S.lf(i, 1, j, t);
-    src_ff(S, j, t);
-    uint64_t lenj = S.len(j);
-    while (rem > 0) {
-        const uint64_t avail = (j < S.rows() - 1 && t < lenj) ? lenj - t : rem;  // the last row absorbs everything
-        uint64_t take = avail < rem ? avail : rem;
-        while (ci < nc && cut[ci] <= b) ++ci;                                   // thresholds inside the row
-        if (ci < nc && cut[ci] - b < take) take = cut[ci] - b;
-        rem -= take;
-        while (take > 0) {               // cut pieces longer than kSKMaxLen
-            const uint64_t piece = take < kSKMaxLen ? take : kSKMaxLen;
-            f(b, (uint32_t)piece, j, t);
-            b += piece;
-            t += piece;
-            take -= piece;
-        }
-        if (rem > 0 && t >= lenj && j < S.rows() - 1) {
-            ++j;
-            t = 0;
-            lenj = S.len(j);
-        }
-    }
-}
-
-template <class Src>
-__global__ __launch_bounds__(256) void sk_count_kernel(Src S, uint32_t *__restrict__ count) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= S.rows()) return;
-    uint32_t pieces = 0;
-    for_each_piece(S, (uint32_t)i, [&](uint64_t, uint32_t, uint32_t, uint64_t) { ++pieces; });
-    count[i] = pieces;
-}
-
-// Block-level exclusive scan of 1024 items per block; block totals go to `totals`.
-__global__ __launch_bounds__(256) void scan_block_kernel(uint32_t *__restrict__ data, uint64_t n,
-                                                         uint32_t *__restrict__ totals) {
-    __shared__ uint32_t s_sum[256];
-    const uint64_t base = (uint64_t)blockIdx.x * 1024 + (uint64_t)threadIdx.x * 4;
-    uint32_t v[4], run = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        v[q] = base + q < n ? data[base + q] : 0;
-        const uint32_t x = v[q];
-        v[q] = run;
-        run += x;
-    }
-    s_sum[threadIdx.x] = run;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {   // Hillis-Steele over the 256 per-thread sums
-        const uint32_t add = threadIdx.x >= d ? s_sum[threadIdx.x - d] : 0;
-        __syncthreads();
-        s_sum[threadIdx.x] += add;
-        __syncthreads();
-    }
-    const uint32_t before = threadIdx.x ? s_sum[threadIdx.x - 1] : 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (base + q < n) data[base + q] = v[q] + before;
-    if (threadIdx.x == 255) totals[blockIdx.x] = s_sum[255];
-}
-
-__global__ __launch_bounds__(256) void scan_add_kernel(uint32_t *__restrict__ data, uint64_t n,
-                                                       const uint32_t *__restrict__ block_off) {
-    const uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint64_t k = i + (uint64_t)q * 256;
-        if (k < n) data[k] += block_off[blockIdx.x];
-    }
-}
 
 template <int K>
 __device__ __forceinline__ uint32_t *sk_row_ptr(uint8_t *lines, uint32_t j) {
@@ -239,16 +105,6 @@ __global__ __launch_bounds__(256) void sk_emit_kernel(Src S, const uint32_t *__r
         p[kL + 1] = 0xFFFFFFFFu;
         idx_new[r_new] = S.n();
     }
-}
-
-// New row holding BWT position `pos`, which lies in source row j.
-__device__ __forceinline__ uint32_t sk_find(const uint64_t *idx_new, const uint32_t *first, uint32_t j, uint64_t pos) {
-    uint32_t lo = first[j], hi = first[j + 1];   // rows lo .. hi-1 tile source row j
-    while (hi - lo > 1) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (idx_new[mid] <= pos) lo = mid; else hi = mid;
-    }
-    return lo;
 }
 
 template <class Src, int K>
@@ -376,71 +232,48 @@ __global__ __launch_bounds__(256) void sk_hint_kernel(SKTable T, uint8_t *lines_
     p[kL + 2] = (w.d[kL + 2] & 0x00FFFF00u) | (hints << 24) | (dists >> 24);      // slot 3
 }
 
-#define SK_TRY(expr)                                                          \
-    do {                                                                      \
-        hipError_t e_ = (expr);                                               \
-        if (e_ != hipSuccess) {                                               \
-            err = std::string(#expr) + ": " + hipGetErrorString(e_);          \
-            return false;                                                     \
-        }                                                                     \
-    } while (0)
-
 // One refinement pass.  `finish` = also build jump tables, hints and distances (a level
-// that is only the source of the next one does not need them).
+// that is only the source of the next one does not need them).  Returns COLBWT_OK,
+// COLBWT_ERR_NOMEM (HBM or the 2^32-2 row limit: a shallower layout may still fit) or
+// COLBWT_ERR_HIP (anything else: retrying would only hide it).
 template <class Src, int K>
-bool build_level(const Src &S, uint64_t src_rows, const uint8_t *d_cmap, uint32_t sigma, const HintChars &chars,
-                 bool finish, SKTable &out, SKBuffers &buf, std::string &err) {
+int build_level(const Src &S, uint64_t src_rows, const uint8_t *d_cmap, uint32_t sigma, const HintChars &chars,
+                bool finish, SKTable &out, SKBuffers &buf, std::string &err) {
     const uint64_t r = src_rows;
-    uint32_t *d_first = nullptr, *d_tot = nullptr;
-    SK_TRY(hipMalloc((void **)&d_first, (r + 1) * sizeof(uint32_t)));
-    const uint32_t rblocks = (uint32_t)((r + 255) / 256);
-    hipLaunchKernelGGL(sk_count_kernel<Src>, dim3(rblocks), dim3(256), 0, 0, S, d_first);
-    SK_TRY(hipGetLastError());
-    SK_TRY(hipMemset(d_first + r, 0, sizeof(uint32_t)));   // the extra slot receives the total
-    const uint64_t nscan = r + 1;
-    const uint32_t sblocks = (uint32_t)((nscan + 1023) / 1024);
-    SK_TRY(hipMalloc((void **)&d_tot, sblocks * sizeof(uint32_t)));
-    hipLaunchKernelGGL(scan_block_kernel, dim3(sblocks), dim3(256), 0, 0, d_first, nscan, d_tot);
-    SK_TRY(hipStreamSynchronize(0));
-    std::vector<uint32_t> tot(sblocks);
-    SK_TRY(hipMemcpy(tot.data(), d_tot, sblocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    DevPtr first_buf;
     uint64_t run = 0;
-    for (uint32_t b = 0; b < sblocks; ++b) {
-        const uint64_t x = tot[b];
-        tot[b] = (uint32_t)run;
-        run += x;
+    {
+        const int rc = count_and_scan(S, r, first_buf, run, err);
+        if (rc != COLBWT_OK) return rc;
     }
     if (run > 0xFFFFFFFEull) {
-        (void)hipFree(d_first);
-        (void)hipFree(d_tot);
         err = std::to_string(K) + "-step layout needs " + std::to_string(run) + " rows (> 2^32-2)";
-        return false;
+        return COLBWT_ERR_NOMEM;
     }
-    SK_TRY(hipMemcpy(d_tot, tot.data(), sblocks * sizeof(uint32_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(scan_add_kernel, dim3(sblocks), dim3(256), 0, 0, d_first, nscan, d_tot);
-    SK_TRY(hipStreamSynchronize(0));
-    (void)hipFree(d_tot);
+    uint32_t *d_first = first_buf.as<uint32_t>();
+    const uint32_t rblocks = (uint32_t)((r + 255) / 256);
     const uint32_t r_new = (uint32_t)run;
 
     constexpr uint32_t rpl = SKGeom<K>::kRowsPerLine;
     const uint64_t nlines = ((uint64_t)r_new + 1 + rpl - 1) / rpl + 1;
-    SK_TRY(hipMalloc(&buf.lines, nlines * 128));
-    SK_TRY(hipMemset(buf.lines, 0, nlines * 128));
-    SK_TRY(hipMalloc(&buf.idx, ((uint64_t)r_new + 4) * sizeof(uint64_t)));
-    SK_TRY(hipMemset(buf.idx, 0xFF, ((uint64_t)r_new + 4) * sizeof(uint64_t)));
-    SK_TRY(hipMalloc(&buf.thr, (uint64_t)r_new * sizeof(uint64_t)));
-    hipLaunchKernelGGL((sk_emit_kernel<Src, K>), dim3(rblocks), dim3(256), 0, 0, S, d_first, (uint8_t *)buf.lines,
-                       (uint64_t *)buf.idx, (uint64_t *)buf.thr, r_new);
+    SK_TRY(buf.lines.alloc(nlines * 128));
+    SK_TRY(hipMemset(buf.lines.get(), 0, nlines * 128));
+    SK_TRY(buf.idx.alloc(((uint64_t)r_new + 4) * sizeof(uint64_t)));
+    SK_TRY(hipMemset(buf.idx.get(), 0xFF, ((uint64_t)r_new + 4) * sizeof(uint64_t)));
+    SK_TRY(buf.thr.alloc(((uint64_t)r_new + 1) * sizeof(uint64_t)));
+    uint8_t *const d_lines = buf.lines.as<uint8_t>();
+    uint64_t *const d_idx = buf.idx.as<uint64_t>(), *const d_thr = buf.thr.as<uint64_t>();
+    hipLaunchKernelGGL((sk_emit_kernel<Src, K>), dim3(rblocks), dim3(256), 0, 0, S, d_first, d_lines, d_idx, d_thr, r_new);
     SK_TRY(hipStreamSynchronize(0));
     const uint32_t nblocks = (uint32_t)(((uint64_t)r_new + 255) / 256);
-    hipLaunchKernelGGL((sk_link_kernel<Src, K>), dim3(nblocks), dim3(256), 0, 0, S, d_first, (uint8_t *)buf.lines,
-                       (const uint64_t *)buf.idx, r_new);
+    hipLaunchKernelGGL((sk_link_kernel<Src, K>), dim3(nblocks), dim3(256), 0, 0, S, d_first, d_lines,
+                       (const uint64_t *)d_idx, r_new);
     SK_TRY(hipStreamSynchronize(0));
-    (void)hipFree(d_first);
+    first_buf.reset();
 
-    out.lines = (const uint8_t *)buf.lines;
-    out.idx = (const uint64_t *)buf.idx;
-    out.thr = (const uint64_t *)buf.thr;
+    out.lines = d_lines;
+    out.idx = d_idx;
+    out.thr = d_thr;
     out.cmap = d_cmap;
     out.n = S.T.n;
     out.r = r_new;
@@ -448,58 +281,104 @@ bool build_level(const Src &S, uint64_t src_rows, const uint8_t *d_cmap, uint32_
     out.nblk = (uint32_t)(((uint64_t)r_new + sk_block_rows<K>() - 1) / sk_block_rows<K>());
     out.steps = K;
     out.next_tbl = out.prev_tbl = nullptr;
-    buf.bytes = nlines * 128 + (2 * (uint64_t)r_new + 4) * sizeof(uint64_t);
-    if (!finish) return true;
+    if (!finish) return COLBWT_OK;
 
     const uint64_t entries = (uint64_t)out.nblk * out.sigma;
-    SK_TRY(hipMalloc(&buf.next, (entries ? entries : 1) * sizeof(uint32_t)));
-    SK_TRY(hipMalloc(&buf.prev, (entries ? entries : 1) * sizeof(uint32_t)));
-    out.next_tbl = (const uint32_t *)buf.next;
-    out.prev_tbl = (const uint32_t *)buf.prev;
-    hipLaunchKernelGGL(sk_block_first_last_kernel<K>, dim3((out.nblk + 3) / 4), dim3(256), 0, 0, out,
-                       (uint32_t *)buf.next, (uint32_t *)buf.prev);
+    SK_TRY(buf.next.alloc((entries ? entries : 1) * sizeof(uint32_t)));
+    SK_TRY(buf.prev.alloc((entries ? entries : 1) * sizeof(uint32_t)));
+    uint32_t *const d_next = buf.next.as<uint32_t>(), *const d_prev = buf.prev.as<uint32_t>();
+    out.next_tbl = d_next;
+    out.prev_tbl = d_prev;
+    hipLaunchKernelGGL(sk_block_first_last_kernel<K>, dim3((out.nblk + 3) / 4), dim3(256), 0, 0, out, d_next, d_prev);
     SK_TRY(hipStreamSynchronize(0));
     {
         std::vector<uint32_t> first(entries), last(entries), next, prev;
-        SK_TRY(hipMemcpy(first.data(), buf.next, entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        SK_TRY(hipMemcpy(last.data(), buf.prev, entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        SK_TRY(hipMemcpy(first.data(), buf.next.get(), entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        SK_TRY(hipMemcpy(last.data(), buf.prev.get(), entries * sizeof(uint32_t), hipMemcpyDeviceToHost));
         finish_jump_tables(first, last, out.nblk, out.sigma, next, prev);
-        SK_TRY(hipMemcpy(buf.next, next.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
-        SK_TRY(hipMemcpy(buf.prev, prev.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        SK_TRY(hipMemcpy(buf.next.get(), next.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
+        SK_TRY(hipMemcpy(buf.prev.get(), prev.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    hipLaunchKernelGGL(sk_hint_kernel<K>, dim3(nblocks), dim3(256), 0, 0, out, (uint8_t *)buf.lines, chars);
+    hipLaunchKernelGGL(sk_hint_kernel<K>, dim3(nblocks), dim3(256), 0, 0, out, d_lines, chars);
     SK_TRY(hipGetLastError());
     SK_TRY(hipStreamSynchronize(0));
-    buf.bytes += 2 * (entries ? entries : 1) * sizeof(uint32_t);
-    return true;
+    return COLBWT_OK;
+}
+
+template <int K>
+struct SKView {
+    SKTable T;
+    __device__ __forceinline__ uint64_t n() const { return T.n; }
+    __device__ __forceinline__ uint32_t rows() const { return T.r; }
+    __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
+    __device__ __forceinline__ SKRow<K> load(uint32_t j) const { return sk_load<K>(T, j); }
+    __device__ __forceinline__ uint32_t ch(const SKRow<K> &w) const { return sk_char<K>(w); }
+    __device__ __forceinline__ uint32_t lf_row(const SKRow<K> &w) const { return sk_I<K>(w, 1); }
+    __device__ __forceinline__ uint32_t lf_off(const SKRow<K> &w) const { return sk_O<K>(w, 1); }
+    __device__ __forceinline__ uint64_t len(uint32_t, const SKRow<K> &w) const { return sk_len<K>(w); }
+};
+
+// The read sampler over a K-step table (read_sampler.h): the one-step tables are freed once the
+// refined rows exist.
+template <int K>
+__global__ __launch_bounds__(256) void sk_synth_reads_kernel(SKView<K> V, uint64_t n_reads, uint32_t m, uint32_t sub_permille,
+                                                             uint64_t seed, uint8_t *__restrict__ bases,
+                                                             uint64_t *__restrict__ read_off) {
+    const uint64_t rd = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (rd > n_reads) return;
+    read_off[rd] = rd * m;
+    if (rd == n_reads) return;
+    sample_read(V, rd, m, sub_permille, seed, bases + rd * m);
 }
 
 }  // namespace
 
-void SKBuffers::release() {
-    for (void **p : {&lines, &idx, &thr, &next, &prev}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
-    bytes = 0;
+void launch_sk_synth_reads(const SKTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille, uint64_t seed,
+                           uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream) {
+    const uint32_t blocks = (uint32_t)((n_reads + 1 + 255) / 256);
+    if (T.steps == 3)
+        hipLaunchKernelGGL(sk_synth_reads_kernel<3>, dim3(blocks), dim3(256), 0, stream, SKView<3>{T}, n_reads, read_len,
+                           sub_permille, seed, d_bases, d_read_off);
+    else
+        hipLaunchKernelGGL(sk_synth_reads_kernel<2>, dim3(blocks), dim3(256), 0, stream, SKView<2>{T}, n_reads, read_len,
+                           sub_permille, seed, d_bases, d_read_off);
 }
 
-// Builds the `steps`-step layout (2 or 3) from the one-step tables of `T`.  Returns false
-// with `err` set when it cannot (more than 2^32-2 rows, out of memory).
-bool build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err) {
+void SKBuffers::release() {
+    for (DevPtr *p : {&lines, &idx, &thr, &next, &prev}) p->reset();
+}
+
+uint64_t SKBuffers::bytes() const {
+    return lines.bytes() + idx.bytes() + thr.bytes() + next.bytes() + prev.bytes();
+}
+
+// Builds the `steps`-step layout (2 or 3) from the one-step tables of `T`.  Returns COLBWT_OK or
+// the code of what went wrong with `err` set; on failure nothing stays allocated.  Once the last
+// pass that reads the one-step tables is done, `source_done` is called: the owner frees them
+// before the next level is allocated (they are not needed by the K-step query).
+int build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out, SKBuffers &buf, std::string &err,
+             const std::function<void()> &source_done) {
     SrcL1 s1{T, chars};
-    if (steps == 2) return build_level<SrcL1, 2>(s1, T.r, T.cmap, T.sigma, chars, true, out, buf, err);
-    // level 3 is refined from a temporary level 2
-    SKTable t2{};
-    SKBuffers b2;
-    bool ok = build_level<SrcL1, 2>(s1, T.r, T.cmap, T.sigma, chars, false, t2, b2, err);
-    if (ok) {
-        SrcSK<2> s2{t2};
-        ok = build_level<SrcSK<2>, 3>(s2, t2.r, T.cmap, T.sigma, chars, true, out, buf, err);
+    const uint8_t *cmap = T.cmap;
+    const uint32_t sigma = T.sigma;
+    int rc;
+    if (steps == 2) {
+        rc = build_level<SrcL1, 2>(s1, T.r, cmap, sigma, chars, true, out, buf, err);
+        if (rc == COLBWT_OK) source_done();
+    } else {
+        // level 3 is refined from a temporary level 2
+        SKTable t2{};
+        SKBuffers b2;
+        rc = build_level<SrcL1, 2>(s1, T.r, cmap, sigma, chars, false, t2, b2, err);
+        if (rc == COLBWT_OK) {
+            source_done();
+            SrcSK<2> s2{t2};
+            rc = build_level<SrcSK<2>, 3>(s2, t2.r, cmap, sigma, chars, true, out, buf, err);
+        }
+        b2.release();
     }
-    b2.release();
-    if (!ok) buf.release();
-    return ok;
+    if (rc != COLBWT_OK) buf.release();
+    return rc;
 }
 
 }  // namespace colbwt

@@ -30,3 +30,11 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def c2_image(pkg):
+    """The BASELINE configs[1] index (2e8 rows, SURVEY.md 8(d) recipe, seed 42) as a .col_pml
+    image in host memory, generated once per session (3.6 GB)."""
+    rows = int(os.environ.get("COLBWT_TEST_ROWS", "200000000"))
+    return pkg.synth_index(rows, mean_len=8, split_permille=0, seed=42)

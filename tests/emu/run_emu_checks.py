@@ -204,6 +204,55 @@ def main():
         except pkg.ColbwtError as e:
             assert e.code == -3, (label, e)
     print("ok loader validation")
+
+    # 8. the read sampler gives the same reads from every layout (the K-step index no longer
+    #    holds the one-step tables)
+    img = pkg.synth_index(1200, mean_len=6, split_permille=80, seed=31)
+    got = []
+    for layout in (1, 2, 3):
+        tbl = pkg.ColPml.from_bytes(img, layout=layout)
+        b = np.zeros(300 * 90 + 64, np.uint8)
+        o = np.zeros(301, np.uint64)
+        tbl.synth_reads_device(300, 90, 20, 77, b.ctypes.data, o.ctypes.data)
+        got.append(b[:300 * 90].copy())
+        assert np.array_equal(o, np.arange(301, dtype=np.uint64) * 90)
+        tbl.close()
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
+    print("ok sampler: identical reads from layouts 1, 2, 3")
+
+    # 9. HBM budget (COLBWT_HBM_BUDGET_MB): AUTO falls back to the deepest layout that fits; an
+    #    explicit layout that does not fit is COLBWT_ERR_NOMEM; nothing is left allocated
+    img = pkg.synth_index(2_500, mean_len=8, split_permille=0, seed=5)
+    reads = helpers.backward_walk_reads(img, 40, 60, 0.02, seed=5)
+    bases, off = helpers.concat_reads(reads)
+    epml, ecid = oracle.OracleIndex(bytes(img)).query_batch(bases, off)
+    full = {}
+    for layout in (1, 2, 3):
+        tbl = pkg.ColPml.from_bytes(img, layout=layout)
+        full[layout] = tbl.info().device_bytes
+        tbl.close()
+    assert full[1] < full[2] < full[3]
+    for budget_mb, expect in ((10_000, 3), (full[3] / 2**20 - 0.01, 2), (full[2] / 2**20 - 0.01, 1)):
+        os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)
+        tbl = pkg.ColPml.from_bytes(img, layout=0)
+        assert tbl.info().layout == expect, (budget_mb, tbl.info().layout, full)
+        pml, cid, _ = tbl.query_batch(bases, off)
+        assert np.array_equal(pml, epml) and np.array_equal(cid, ecid)
+        tbl.close()
+    os.environ["COLBWT_HBM_BUDGET_MB"] = str(full[2] / 2**20)
+    try:
+        pkg.ColPml.from_bytes(img, layout=3)
+        raise SystemExit("a three-step open beyond the budget must fail")
+    except pkg.ColbwtError as e:
+        assert e.code == -6, e
+    os.environ["COLBWT_HBM_BUDGET_MB"] = "0.05"
+    try:
+        pkg.ColPml.from_bytes(img, layout=0)
+        raise SystemExit("nothing fits in 50 KB")
+    except pkg.ColbwtError as e:
+        assert e.code == -6, e
+    del os.environ["COLBWT_HBM_BUDGET_MB"]
+    print(f"ok HBM budget fallback (index bytes by layout: {full})")
     print("EMU-ALL-OK")
 
 

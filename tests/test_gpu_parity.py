@@ -254,16 +254,15 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
 
 
 @pytest.mark.parametrize("layout", [1, 2, 3])
-def test_full_scale_properties(pkg, oracle, layout):
+def test_full_scale_properties(pkg, oracle, layout, c2_image):
     """BASELINE config C2 scale (2e8 rows): size-independent properties --
     idempotence (two runs, identical bytes), batch-position independence (a
     permuted sub-batch gives the same per-read values) and oracle agreement on
     a sample.  Rows can be lowered with COLBWT_TEST_ROWS for rehearsals."""
     import torch
-    rows = int(os.environ.get("COLBWT_TEST_ROWS", "200000000"))
     n_reads, m = int(os.environ.get("COLBWT_TEST_READS", "2000000")), 150
     dev = torch.device("cuda", 0)
-    image = pkg.synth_index(rows, mean_len=8, split_permille=0, seed=42)
+    image = c2_image
     tbl = pkg.ColPml.from_bytes(image, layout=layout)
     d_bases = torch.zeros(n_reads * m + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
