@@ -220,11 +220,13 @@ def main():
                        "pipeline_chunks": n_chunks,
                        "index_gen_s": round(t_gen, 2), "index_load_s": round(t_load, 2),
                        "index_hbm_bytes": int(info.device_bytes),
-                       "hbm_layout": {1: "one-step", 2: "two-step", 3: "three-step"}.get(info.layout, "?"),
+                       "hbm_layout": {1: "one-step", 2: "two-step", 3: "three-step",
+                                      4: f"line rows K={info.layout_shape >> 8} KS={info.layout_shape & 255}"}.get(info.layout, "?"),
                        "hbm_table_rows": int(info.table_rows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": (f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>"),
+                         "kernel": (f"fat_query_kernel<{info.layout_shape >> 8},{info.layout_shape & 255},u16>" if info.layout == 4
+                                    else f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>"),
                          "avg_launch_ms": avg_launch_ms,
                          "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
                          "bases_per_launch": bases_per_launch, "line_fills": line_fills},

@@ -37,7 +37,7 @@ class ColbwtError(RuntimeError):
 class Info(C.Structure):
     _fields_ = [("bwt_r", C.c_uint64), ("n", C.c_uint64), ("r", C.c_uint64), ("sigma", C.c_uint32),
                 ("device", C.c_uint32), ("device_bytes", C.c_uint64), ("layout", C.c_uint32),
-                ("reserved_", C.c_uint32), ("table_rows", C.c_uint64)]
+                ("layout_shape", C.c_uint32), ("table_rows", C.c_uint64)]
 
 
 class Stats(C.Structure):

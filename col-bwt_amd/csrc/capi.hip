@@ -28,7 +28,8 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_THREE_STEP
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_LINE_ROWS
+constexpr int kDefaultLineSteps = 8;
 
 struct colbwt_index {
     Index ix;
@@ -242,7 +243,9 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         API_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     API_HIP(hipEventRecord(ev[1], stream));
-    if (idx->ix.layout() >= 2)
+    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+        launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
@@ -360,9 +363,21 @@ const char *colbwt_version(void) { return "colbwt-mi355x 0.1.0 (gfx950)"; }
 const char *colbwt_last_error(void) { return g_err.c_str(); }
 
 static int default_layout() {
-    const char *e = getenv("COLBWT_LAYOUT");   // override: 1 = one-step, 2 / 3 = K-step rows
-    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '3') && e[1] == 0) return e[0] - '0';
+    const char *e = getenv("COLBWT_LAYOUT");   // override: 1 = one-step, 2 / 3 = K-step rows, 4 = line rows
+    if (e && e[0] >= '1' && e[0] <= '4' && e[1] == 0) return e[0] - '0';
     return COLBWT_LAYOUT_DEFAULT_CHOICE;
+}
+
+// Own steps K of a line-row open: from the layout argument, else COLBWT_LINE_ROWS_STEPS
+// (experiments), else the default.
+static int line_rows_steps(int layout_arg) {
+    int steps = (layout_arg >> 8) & 0xFF;
+    if (steps == 0) {
+        steps = kDefaultLineSteps;
+        const char *e = getenv("COLBWT_LINE_ROWS_STEPS");
+        if (e && e[0] >= '2' && e[0] <= '8' && e[1] == 0) steps = e[0] - '0';
+    }
+    return steps;
 }
 
 int colbwt_index_open_memory(const void *bytes, uint64_t len, const colbwt_widths *widths, int device,
@@ -375,18 +390,22 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     if (!out) return fail(COLBWT_ERR_ARG, "null out");
     const bool automatic = layout == COLBWT_LAYOUT_AUTO;
     if (automatic) layout = default_layout();
-    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_THREE_STEP) return fail(COLBWT_ERR_ARG, "bad layout");
+    const int steps = line_rows_steps(layout);
+    layout &= 0xFF;
+    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_LINE_ROWS) return fail(COLBWT_ERR_ARG, "bad layout");
+    if (layout == COLBWT_LAYOUT_LINE_ROWS && !fat_steps_supported(steps))
+        return fail(COLBWT_ERR_ARG, "line rows: own steps must be 4..8");
     *out = nullptr;
     if (!widths_ok(widths))
         return fail(COLBWT_ERR_ARG, "only the shipped widths BWT_BYTES=5 RUN_BYTES=4 LEN_BYTES=2 ID_BITS=8 are supported");
     colbwt_index *idx = new (std::nothrow) colbwt_index();
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
-    int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
+    int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
     while (rc == COLBWT_ERR_NOMEM && automatic && layout > COLBWT_LAYOUT_ONE_STEP) {
-        // the K-step table does not fit (HBM, or more than 2^32-2 refined rows): one step fewer
+        // the table does not fit (HBM, or more than 2^32-2 refined rows): the next smaller layout
         --layout;
-        rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err);
+        rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
     }
     if (rc != COLBWT_OK) {
         delete idx;
@@ -428,7 +447,9 @@ int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
     out->device = (uint32_t)idx->ix.device();
     out->device_bytes = idx->ix.device_bytes();
     out->layout = (uint32_t)idx->ix.layout();
-    out->reserved_ = 0;
+    out->layout_shape = idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS
+                            ? (idx->ix.table_fat().steps << 8) | kFatSlotSteps
+                            : 0;
     out->table_rows = idx->ix.table_rows();
     return COLBWT_OK;
 }
@@ -470,7 +491,9 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
         API_HIP(hipEventCreate(&e1));
         API_HIP(hipEventRecord(e0, stream));
     }
-    if (idx->ix.layout() >= 2)
+    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+        launch_fat_query(idx->ix.table_fat(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+    else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
@@ -660,7 +683,9 @@ int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 64, stream));
-    if (idx->ix.layout() >= 2)   // the one-step tables are gone once the K-step rows exist
+    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+        launch_fat_synth_reads(idx->ix.table_fat(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
+    else if (idx->ix.layout() >= 2)   // the one-step tables are gone once the K-step rows exist
         launch_sk_synth_reads(idx->ix.table_k(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
     else
         launch_synth_reads(idx->ix.table(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);

@@ -5,7 +5,7 @@
 //           (row, offset) of LF(first position), char | col id, threshold;
 //   chars   byte-per-row character array of level K and its per-block jump tables;
 //   pack    one thread per level-K row chases LF through the plain level K: K steps from the
-//           row's first position (landings, characters, col ids, cuts) and KS steps from each
+//           row's first position (landings, characters, col ids, cuts) and two steps from each
 //           of the three mismatch targets.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -151,9 +151,8 @@ __device__ __forceinline__ void plain_lf(const PlainLevel &P, uint32_t &j, uint6
 __device__ __forceinline__ void put_byte(uint32_t *w, uint32_t off, uint32_t v) { w[off >> 2] |= (v & 0xFFu) << (8 * (off & 3u)); }
 __device__ __forceinline__ void put_half(uint32_t *w, uint32_t off, uint32_t v) { w[off >> 2] |= (v & 0xFFFFu) << (8 * (off & 2u)); }
 
-template <int K, int KS>
+template <int K>
 __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T, uint8_t *__restrict__ lines) {
-    using G = FatGeom<K, KS>;
     const uint64_t i64 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i64 >= P.r) return;
     const uint32_t i = (uint32_t)i64;
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
 #pragma unroll
     for (uint32_t q = 0; q < kFatRowBytes / 4; ++q) w[q] = 0;
     const uint64_t lo = P.idx[i], len = P.idx[(uint64_t)i + 1] - lo;
-    put_half(w, G::kLenOff, (uint32_t)len);
+    put_half(w, kFatLen, (uint32_t)len);
 
     // ---- the row's own K steps
     uint32_t j = i;
@@ -171,11 +170,11 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
     for (int s = 1; s <= K; ++s) {
         const uint32_t meta = P.meta[j];
         if (s == 1) own_ch = meta & 0xFFu;
-        put_byte(w, G::kCh0 + (s - 1), meta & 0xFFu);
-        put_byte(w, G::kCid0 + (s - 1), meta >> 8);
+        put_byte(w, kFatCh + (8 - s), meta & 0xFFu);
+        put_byte(w, kFatCid + (8 - s), meta >> 8);
         plain_lf(P, j, t);                                   // (j, t) = LF^s(first position)
-        w[s - 1] = j;
-        put_half(w, G::kHalf0 + 2 * (s - 1), (uint32_t)t);
+        w[kFatI / 4 + (s - 1)] = j;
+        put_half(w, kFatO + 2 * (s - 1), (uint32_t)t);
         // where the image of the row leaves row j and row j + 1 (sk_layout.h)
         uint32_t cut = kSKCutNone, len_b = kSKCutNone;
         if ((uint64_t)j + 1 < P.r) {
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
                 }
             }
         }
-        put_byte(w, G::kCut0 + (s - 1), cut | (len_b << 4));
+        put_byte(w, kFatCut + (s - 1), cut | (len_b << 4));
     }
 
     // ---- the mismatch slots: col_pml::threshold_step (col_bwt.hpp:531-574) resolved per row
@@ -215,20 +214,18 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
         }                                                                // else: the threshold is inside the row
         if (tj == kNone) continue;                                       // the query decides at run time
         flags |= 1u << slot;
-        const uint32_t sb = G::kSlot0 + slot * G::kSlotBytes;
-#pragma unroll
-        for (int a = 1; a <= KS; ++a) {
-            if (a >= 2) {
-                const uint32_t meta = P.meta[tj];
-                put_byte(w, sb + G::kSlotCh0 + (a - 2), meta & 0xFFu);
-                put_byte(w, sb + G::kSlotCid0 + (a - 2), meta >> 8);
-            }
-            plain_lf(P, tj, to);
-            w[(sb >> 2) + (a - 1)] = tj;
-            put_half(w, sb + G::kSlotP0 + 2 * (a - 1), (uint32_t)to);
-        }
+        const uint32_t sb = kFatSlot0 + slot * kFatSlotBytes;
+        plain_lf(P, tj, to);                                             // LF(p_c)
+        w[sb >> 2] = tj;
+        put_half(w, sb + kFatSlotP, (uint32_t)to);
+        const uint32_t meta = P.meta[tj];                                // met after one step
+        put_byte(w, sb + kFatSlotCh2, meta & 0xFFu);
+        put_byte(w, sb + kFatSlotCid2, meta >> 8);
+        plain_lf(P, tj, to);                                             // LF^2(p_c)
+        w[(sb >> 2) + 1] = tj;
+        put_half(w, sb + kFatSlotP + 2, (uint32_t)to);
     }
-    put_byte(w, G::kFlags, flags);
+    put_byte(w, kFatFlags, flags);
     uint4 *dst = reinterpret_cast<uint4 *>(lines + (uint64_t)i * kFatRowBytes);
 #pragma unroll
     for (uint32_t q = 0; q < kFatRowBytes / 16; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
@@ -278,8 +275,8 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
     return COLBWT_OK;
 }
 
-template <int K, int KS>
-int build_fat_shape(const DevTable &T1, const HintChars &chars, FatTable &out, FatBuffers &buf, std::string &err,
+template <int K>
+int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, FatBuffers &buf, std::string &err,
                     const std::function<void()> &source_done) {
     const uint8_t *cmap = T1.cmap;
     const uint32_t sigma = T1.sigma;
@@ -314,7 +311,6 @@ int build_fat_shape(const DevTable &T1, const HintChars &chars, FatTable &out, F
     out.cmap = cmap;
     out.nblk = (uint32_t)(((uint64_t)r + (1u << kBlockShift) - 1) >> kBlockShift);
     out.steps = K;
-    out.slot_steps = KS;
     out.top4 = 0;
     for (uint32_t k = 0; k < 4; ++k) out.top4 |= (uint32_t)chars.c[k < sigma ? k : 0] << (8 * k);
 
@@ -345,10 +341,12 @@ int build_fat_shape(const DevTable &T1, const HintChars &chars, FatTable &out, F
     out.idx = cur.idx;
     out.thr = cur.thr;
 
+    SK_TRY(buf.claim.alloc((uint64_t)kFatClaimSets * kFatClaimBlocks * sizeof(uint32_t)));
+    out.claim = buf.claim.as<uint32_t>();
     SK_TRY(buf.lines.alloc(((uint64_t)r + 1) * kFatRowBytes));
     uint8_t *const d_lines = buf.lines.as<uint8_t>();
     SK_TRY(hipMemset(d_lines + (uint64_t)r * kFatRowBytes, 0, kFatRowBytes));
-    hipLaunchKernelGGL((fat_pack_kernel<K, KS>), dim3(nblocks), dim3(256), 0, 0, cur, out, d_lines);
+    hipLaunchKernelGGL(fat_pack_kernel<K>, dim3(nblocks), dim3(256), 0, 0, cur, out, d_lines);
     SK_TRY(hipGetLastError());
     SK_TRY(hipStreamSynchronize(0));
     out.lines = d_lines;
@@ -359,7 +357,6 @@ int build_fat_shape(const DevTable &T1, const HintChars &chars, FatTable &out, F
 }
 
 // ---- read sampler over line rows (read_sampler.h) ---------------------------------------
-template <int K, int KS>
 struct FatView {
     FatTable T;
     struct Row {
@@ -369,12 +366,11 @@ struct FatView {
     __device__ __forceinline__ uint32_t rows() const { return T.r; }
     __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
     __device__ __forceinline__ Row load(uint32_t j) const {
-        using G = FatGeom<K, KS>;
         const uint32_t *p = reinterpret_cast<const uint32_t *>(T.lines + (uint64_t)j * kFatRowBytes);
         Row w;
-        w.i1 = p[0];
-        w.o1_len = (fat_half(p, G::kHalf0)) | (fat_half(p, G::kLenOff) << 16);
-        w.ch = fat_byte(p, G::kCh0);
+        w.i1 = p[kFatI / 4];
+        w.o1_len = fat_half(p, kFatO) | (fat_half(p, kFatLen) << 16);
+        w.ch = fat_byte(p, kFatCh + 7);
         return w;
     }
     __device__ __forceinline__ uint32_t ch(const Row &w) const { return w.ch; }
@@ -383,8 +379,7 @@ struct FatView {
     __device__ __forceinline__ uint64_t len(uint32_t, const Row &w) const { return w.o1_len >> 16; }
 };
 
-template <int K, int KS>
-__global__ __launch_bounds__(256) void fat_synth_reads_kernel(FatView<K, KS> V, uint64_t n_reads, uint32_t m, uint32_t sub_permille,
+__global__ __launch_bounds__(256) void fat_synth_reads_kernel(FatView V, uint64_t n_reads, uint32_t m, uint32_t sub_permille,
                                                               uint64_t seed, uint8_t *__restrict__ bases,
                                                               uint64_t *__restrict__ read_off) {
     const uint64_t rd = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -397,30 +392,28 @@ __global__ __launch_bounds__(256) void fat_synth_reads_kernel(FatView<K, KS> V, 
 }  // namespace
 
 void FatBuffers::release() {
-    for (DevPtr *p : {&lines, &chr, &idx, &thr, &next, &prev}) p->reset();
+    for (DevPtr *p : {&lines, &chr, &idx, &thr, &next, &prev, &claim}) p->reset();
 }
 
 uint64_t FatBuffers::bytes() const {
-    return lines.bytes() + chr.bytes() + idx.bytes() + thr.bytes() + next.bytes() + prev.bytes();
+    return lines.bytes() + chr.bytes() + idx.bytes() + thr.bytes() + next.bytes() + prev.bytes() + claim.bytes();
 }
 
-#define COLBWT_FAT_SHAPES(X) X(4, 3) X(5, 2) X(5, 3) X(6, 2) X(7, 2) X(8, 2)
-
-bool fat_shape_supported(int steps, int slot_steps) {
-#define X(K, KS) if (steps == K && slot_steps == KS) return true;
-    COLBWT_FAT_SHAPES(X)
+bool fat_steps_supported(int steps) {
+#define X(K) if (steps == K) return true;
+    COLBWT_FAT_STEPS(X)
 #undef X
     return false;
 }
 
-// Builds the line-row layout with `steps` own steps and `slot_steps` per mismatch slot from the
-// one-step tables.  Same contract as build_sk.
-int build_fat(const DevTable &T, const HintChars &chars, int steps, int slot_steps, FatTable &out, FatBuffers &buf,
-              std::string &err, const std::function<void()> &source_done) {
+// Builds the line-row layout with `steps` own steps from the one-step tables.  Same contract as
+// build_sk.
+int build_fat(const DevTable &T, const HintChars &chars, int steps, FatTable &out, FatBuffers &buf, std::string &err,
+              const std::function<void()> &source_done) {
     int rc = COLBWT_ERR_ARG;
-    err = "unsupported line-row shape";
-#define X(K, KS) if (steps == K && slot_steps == KS) rc = build_fat_shape<K, KS>(T, chars, out, buf, err, source_done);
-    COLBWT_FAT_SHAPES(X)
+    err = "unsupported number of line-row steps";
+#define X(K) if (steps == K) rc = build_fat_steps<K>(T, chars, out, buf, err, source_done);
+    COLBWT_FAT_STEPS(X)
 #undef X
     if (rc != COLBWT_OK) buf.release();
     return rc;
@@ -429,12 +422,8 @@ int build_fat(const DevTable &T, const HintChars &chars, int steps, int slot_ste
 void launch_fat_synth_reads(const FatTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille, uint64_t seed,
                             uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream) {
     const uint32_t blocks = (uint32_t)((n_reads + 1 + 255) / 256);
-#define X(K, KS)                                                                                                        \
-    if (T.steps == K && T.slot_steps == KS)                                                                             \
-        hipLaunchKernelGGL((fat_synth_reads_kernel<K, KS>), dim3(blocks), dim3(256), 0, stream, FatView<K, KS>{T}, n_reads, \
-                           read_len, sub_permille, seed, d_bases, d_read_off);
-    COLBWT_FAT_SHAPES(X)
-#undef X
+    hipLaunchKernelGGL(fat_synth_reads_kernel, dim3(blocks), dim3(256), 0, stream, FatView{T}, n_reads, read_len, sub_permille,
+                       seed, d_bases, d_read_off);
 }
 
 }  // namespace colbwt

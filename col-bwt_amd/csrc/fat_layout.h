@@ -16,24 +16,26 @@
 //     where a mismatch on c re-orients to (col_bwt.hpp:531-574) is ONE position p_c for the
 //     whole row -- head of the succeeding c-run or tail of the preceding one, decided by the
 //     row's place relative to the threshold (rows are cut at thresholds, sk_build.hip) -- so
-//     the row also stores the landings of LF .. LF^KS from p_c and the characters / col ids
+//     the row also stores the landings of LF and LF^2 from p_c and the character / col id
 //     met on the way.  A mismatch then costs no line fill of its own: the lane leaves the
-//     row it mismatched in directly for where the reference is KS steps later.
+//     row it mismatched in directly for where the reference is two steps later.
 //
-// Row bytes (little endian; K own steps, KS steps per mismatch slot):
-//   dwords      I[1..K]         level-K row holding LF^s(first position of the row)
-//   halfwords   O[1..K], len    offset of that image inside I[s]; row length (<= 65534)
-//   bytes       ch[1..K]        character met after s-1 LF steps (ch[1] = the row's own)
-//               cid[1..K]       col id reported there (col_bwt.hpp:513)
-//               cut[1..K]       cut_a | len_b << 4 for the jump LF^s (sk_layout.h): where the
-//                               image leaves row I[s] and row I[s] + 1; 15 = none
-//               flags           bit s: mismatch slot s is valid; bits 4-6: dense index of the
-//                               row's character among the four most frequent (7 = other)
-//   (pad to 16)
-//   3 slots     J[1..KS] dwords, P[1..KS] halfwords: exact landing (row, offset) of LF^a(p_c),
-//               fast-forward included (one position: nothing left to cut);
-//               tch[2..KS], tcid[2..KS]: character / col id met after a-1 LF steps from p_c
-//               (pad to 8)
+// Row bytes (little endian; K <= 8 own steps, 2 steps per mismatch slot), laid out for how the
+// query reads them -- two 16-byte pieces always, then one dword, one halfword and one slot:
+//   [  0,   8)  CH    ch[a] at byte 8 - a: the character met after a - 1 LF steps (ch[1] = the
+//                     row's own); compared with the next 8 read bases in one 64-bit XOR
+//   [  8,  16)  CID   cid[a] at byte 8 - a: the col id reported there (col_bwt.hpp:513)
+//   [ 16,  18)  len   row length (<= 65534)
+//   [ 18]       flags bit s: mismatch slot s is valid; bits 4-6: dense index of the row's
+//                     character among the four most frequent (7 = other)
+//   [ 20,  28)  cut[1..8]  cut_a | len_b << 4 for the jump LF^s (sk_layout.h): where the image
+//                     leaves row I[s] and row I[s] + 1; 15 = none
+//   [ 32,  64)  I[1..8]    level-K row holding LF^s(first position of the row)
+//   [ 64,  80)  O[1..8]    offset of that image inside I[s]
+//   [ 80, 128)  3 slots of 16 bytes: J[1..2] dwords, P[1..2] halfwords: exact landing (row,
+//                     offset) of LF^a(p_c), fast-forward included (one position: nothing left to
+//                     cut); tch2, tcid2: character / col id met after one LF step from p_c
+//   entries beyond K are zero.
 // Side arrays (cold: rare characters, read sampler, load-time kernels):
 //   chr[r] u8, idx[r+1] u64 (idx[r] = n), thr[r] u64, next_tbl / prev_tbl per 256-row block.
 #pragma once
@@ -44,31 +46,17 @@
 
 namespace colbwt {
 
+// the numbers of own steps K compiled in
+#define COLBWT_FAT_STEPS(X) X(4) X(5) X(6) X(7) X(8)
+
 constexpr uint32_t kFatRowBytes = 128;
 constexpr uint32_t kFatSlots = 3;
+constexpr uint32_t kFatSlotSteps = 2;
 constexpr uint32_t kFatOwnOther = 7;     // flags bits 4-6: the row's character is not one of the top four
-constexpr uint32_t kFatMaxLen = 65534;
-
-template <int K, int KS>
-struct FatGeom {
-    static_assert(K >= 2 && K <= 8 && KS >= 1 && KS <= K, "supported shapes");
-    static constexpr uint32_t kHalf0 = 4 * K;                                   // byte offset of O[1]
-    static constexpr uint32_t kLenOff = kHalf0 + 2 * K;                         // byte offset of len
-    static constexpr uint32_t kCh0 = (kLenOff + 2 + 3) & ~3u;                   // ch[1..K]
-    static constexpr uint32_t kCid0 = kCh0 + K;                                 // cid[1..K]
-    static constexpr uint32_t kCut0 = kCid0 + K;                                // cut[1..K]
-    static constexpr uint32_t kFlags = kCut0 + K;
-    static constexpr uint32_t kOwnBytes = (kFlags + 1 + 3) & ~3u;
-    static constexpr uint32_t kOwnDwords = kOwnBytes / 4;
-    static constexpr uint32_t kSlot0 = (kOwnBytes + 15) & ~15u;
-    static constexpr uint32_t kSlotRaw = 4 * KS + 2 * KS + 2 * (KS - 1);        // J, P, tch, tcid
-    static constexpr uint32_t kSlotBytes = (kSlotRaw + 7) & ~7u;
-    static constexpr uint32_t kSlotDwords = kSlotBytes / 4;
-    static constexpr uint32_t kSlotP0 = 4 * KS;                                 // inside the slot
-    static constexpr uint32_t kSlotCh0 = kSlotP0 + 2 * KS;                      // tch[2..KS]
-    static constexpr uint32_t kSlotCid0 = kSlotCh0 + (KS - 1);                  // tcid[2..KS]
-    static_assert(kSlot0 + kFatSlots * kSlotBytes <= kFatRowBytes, "row does not fit one line");
-};
+constexpr uint32_t kFatCh = 0, kFatCid = 8, kFatLen = 16, kFatFlags = 18, kFatCut = 20, kFatI = 32, kFatO = 64,
+                   kFatSlot0 = 80, kFatSlotBytes = 16;
+// inside a slot
+constexpr uint32_t kFatSlotP = 8, kFatSlotCh2 = 12, kFatSlotCid2 = 13;
 
 struct FatTable {
     const uint8_t *lines;     // r rows of 128 bytes (+ one zero row)
@@ -83,9 +71,10 @@ struct FatTable {
     uint32_t sigma;
     uint32_t nblk;
     uint32_t steps;           // K
-    uint32_t slot_steps;      // KS
     uint32_t top4;            // the four most frequent characters, byte k = dense index k
+    uint32_t *claim;          // kFatClaimSets x kFatClaimBlocks chunk counters of the query's persistent workgroups
 };
+constexpr uint32_t kFatClaimSets = 16, kFatClaimBlocks = 4096;
 
 // byte / halfword / dword k of a row image held as dwords
 __device__ __forceinline__ uint32_t fat_byte(const uint32_t *w, uint32_t off) { return (w[off >> 2] >> (8 * (off & 3u))) & 0xFFu; }

@@ -27,13 +27,15 @@ public:
 
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
-    // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1).
-    int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err);
+    // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1);
+    // 4 = line rows (fat_layout.h) with `steps` own steps.
+    int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err, int steps = 0);
 
     const DevTable &table() const { return tbl_; }
     const SKTable &table_k() const { return tblk_; }
+    const FatTable &table_fat() const { return tblf_; }
     int layout() const { return layout_; }
-    uint64_t table_rows() const { return layout_ >= 2 ? tblk_.r : tbl_.r; }
+    uint64_t table_rows() const { return layout_ == 4 ? tblf_.r : (layout_ >= 2 ? tblk_.r : tbl_.r); }
     int device() const { return device_; }
     uint64_t bwt_r() const { return bwt_r_; }
     uint64_t n() const { return tbl_.n; }
@@ -48,6 +50,8 @@ private:
     DevTable tbl_{};
     SKTable tblk_{};
     SKBuffers bufk_;
+    FatTable tblf_{};
+    FatBuffers buff_;
     int layout_ = 1;
     uint64_t bwt_r_ = 0;
     int device_ = -1;

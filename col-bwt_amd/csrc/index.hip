@@ -64,11 +64,12 @@ void Index::release() {
     release_one_step();
     d_cmap_.reset();
     bufk_.release();
+    buff_.release();
 }
 
 uint64_t Index::device_bytes() const {
     return d_rows_.bytes() + d_idx_.bytes() + d_thr_.bytes() + d_next_.bytes() + d_prev_.bytes() + d_cmap_.bytes() +
-           bufk_.bytes();
+           bufk_.bytes() + buff_.bytes();
 }
 
 namespace {
@@ -86,7 +87,7 @@ static inline uint64_t rd_u64(const uint8_t *p) {
     return v;
 }
 
-int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err) {
+int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err, int steps) {
     if (!bytes || len < kHeaderBytes) {
         err = "index image shorter than its 32-byte header";
         return COLBWT_ERR_FORMAT;
@@ -230,6 +231,13 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         layout_ = 1;
         if (layout == 2 || layout == 3) {
             rc = build_sk(tbl_, hc, layout, tblk_, bufk_, err, [this] { release_one_step(); });
+            if (rc != COLBWT_OK) {
+                release();
+                return rc;
+            }
+            layout_ = layout;
+        } else if (layout == 4) {
+            rc = build_fat(tbl_, hc, steps, tblf_, buff_, err, [this] { release_one_step(); });
             if (rc != COLBWT_OK) {
                 release();
                 return rc;

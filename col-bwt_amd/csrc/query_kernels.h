@@ -71,15 +71,15 @@ int build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out,
 
 // Device allocations of a line-row table (fat_layout.h).
 struct FatBuffers {
-    DevPtr lines, chr, idx, thr, next, prev;
+    DevPtr lines, chr, idx, thr, next, prev, claim;
     uint64_t bytes() const;
     void release();
 };
-// Line rows with `steps` own steps and `slot_steps` steps per mismatch slot (fat_build.hip); same
-// contract as build_sk.  fat_shape_supported: the shapes compiled in.
-bool fat_shape_supported(int steps, int slot_steps);
-int build_fat(const DevTable &T, const HintChars &chars, int steps, int slot_steps, FatTable &out, FatBuffers &buf,
-              std::string &err, const std::function<void()> &source_done);
+// Line rows with `steps` own steps (fat_build.hip); same contract as build_sk.
+// fat_steps_supported: the step counts compiled in.
+bool fat_steps_supported(int steps);
+int build_fat(const DevTable &T, const HintChars &chars, int steps, FatTable &out, FatBuffers &buf, std::string &err,
+              const std::function<void()> &source_done);
 // The query over line rows (fat_query.hip).
 void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
                       void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);

@@ -59,8 +59,8 @@ typedef struct colbwt_info {
     uint32_t sigma;        /* distinct characters present in the table */
     uint32_t device;       /* HIP device ordinal                       */
     uint64_t device_bytes; /* HBM held by the index                    */
-    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ */
-    uint32_t reserved_;
+    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS */
+    uint32_t layout_shape; /* line rows: own steps << 8 | steps per mismatch slot; else 0 */
     uint64_t table_rows;   /* rows of the HBM table actually queried   */
 } colbwt_info;
 
@@ -93,12 +93,19 @@ int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colb
  * positions) so that a row also knows the characters / col ids of the next one /
  * two steps and the landings of LF^2 / LF^3 -- one 128-byte line fill serves up
  * to K bases while the read keeps matching; about 4x / 7x the HBM footprint.
- * AUTO = the engine's choice: the deepest layout that can be built (fewer than
- * 2^32-1 refined rows, enough HBM). */
+ * AUTO = the engine's choice: line rows when they can be built (fewer than 2^32-1
+ * refined rows at every level, enough HBM), else the deepest K-step layout that can. */
 #define COLBWT_LAYOUT_AUTO 0
 #define COLBWT_LAYOUT_ONE_STEP 1
 #define COLBWT_LAYOUT_TWO_STEP 2
 #define COLBWT_LAYOUT_THREE_STEP 3
+/* LINE_ROWS: one whole 128-byte line per row, fetched lane-cooperatively (8 lanes x 16 bytes per
+ * row, one instruction): up to 8 look-ahead steps and, for the three most frequent other
+ * characters, where a mismatch re-orients to and what the next step meets from there -- a
+ * mismatch costs no line fill of its own.  About 4x the footprint of THREE_STEP.  The depth
+ * (number of look-ahead steps K, 4..8) may be given; 0 = the engine's default. */
+#define COLBWT_LAYOUT_LINE_ROWS 4
+#define COLBWT_LAYOUT_LINE_ROWS_STEPS(K) (COLBWT_LAYOUT_LINE_ROWS | ((K) << 8))
 int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
                              colbwt_index **out);
 int colbwt_index_open_memory_layout(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,

@@ -87,11 +87,30 @@ static inline unsigned long long __ballot(int pred) {
     return emu::ctx.wave->arrive(pred ? (1ull << (emu::ctx.tid.x & 63)) : 0ull);
 }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
+// Cross-lane hand-over through LDS inside one wave: the 64 emulated lanes are OS threads, so the
+// compiler-only barrier of the GPU build is a real one here.
+#define __builtin_amdgcn_wave_barrier() ((void)emu::ctx.wave->arrive(0))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+// v_perm_b32: result byte i = byte (sel >> 8i) & 0xFF of {s0 (4..7), s1 (0..3)}
+static inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+    const uint64_t both = ((uint64_t)s0 << 32) | s1;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) out |= (uint32_t)((both >> (8 * ((sel >> (8 * i)) & 7u))) & 0xFFu) << (8 * i);
+    return out;
+}
+#define __builtin_amdgcn_perm(s0, s1, sel) emu_perm((s0), (s1), (sel))
+// LDS-DMA: `size` bytes per lane from the lane's global address to (wave-uniform LDS base) + lane * size
+#define __builtin_amdgcn_global_load_lds(gptr, ldsptr, size, offset, aux) \
+    memcpy(reinterpret_cast<char *>(ldsptr) + (size_t)(emu::ctx.tid.x & 63) * (size), reinterpret_cast<const char *>(gptr) + (offset), (size))
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o | v; return o;
 }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; *p = o + v; return o;
+}
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); unsigned long long o = *p; *p = o + v; return o;
 }
 static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; if (v < o) *p = v; return o;
@@ -103,6 +122,10 @@ static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
 static inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return hipSuccess; }   // a two-CU chip,
+template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, F, int, size_t) { *n = 1; return hipSuccess; }   // one block each
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) {
     // exact-size allocations so ASan sees every out-of-bounds device access

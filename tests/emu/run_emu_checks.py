@@ -26,14 +26,17 @@ oracle = load_oracle()
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
-def check(image, reads, label, wide=False):
+LINE_ROWS = 4                     # include/colbwt.h COLBWT_LAYOUT_LINE_ROWS (| steps << 8)
+
+
+def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS,)):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
     epml, ecid = ref.query_batch(bases, off, wide=wide)
-    for layout in (1, 2, 3):         # one-step rows / K-step refined rows: identical results
+    for layout in (1, 2, 3) + tuple(extra_layouts):   # one-step rows / K-step refined rows / line rows: identical results
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
-        assert tbl.info().layout == layout
+        assert tbl.info().layout == layout & 0xFF
         pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
         assert np.array_equal(pml, epml), f"{label}/L{layout}: PML differs at {np.flatnonzero(pml != epml)[:5]}"
         assert np.array_equal(cid, ecid), f"{label}/L{layout}: CID differs at {np.flatnonzero(cid != ecid)[:5]}"
@@ -143,7 +146,7 @@ def main():
         reads = helpers.backward_walk_reads(img, 40, 70, 0.02, seed=seed)
         reads += rand_reads(rng, 40, 0, 90)
         reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
-        check(img, reads, f"synth_{rows}_{split}")
+        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS,), 257: (LINE_ROWS | (5 << 8),)}.get(rows, ()))
     img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=8, thr_mode=1)   # thresholds inside rows: cut out
     check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs")
 
@@ -164,7 +167,8 @@ def main():
     # 4b. threshold hints: thresholds inside rows (sigma <= 5, hints on) and sigma = 7 (hints off)
     for label, alpha in (("hints_sigma4", b"ACGT"), ("hints_sigma5", b"\x01ACGT"), ("nohints_sigma7", b"\x01ACGNTac")):
         img = helpers.random_table(rng, 1500, alphabet=alpha)
-        check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label)
+        check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label,
+              extra_layouts=(LINE_ROWS,) if label == "nohints_sigma7" else ())
 
     # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
     r = 600
@@ -182,7 +186,9 @@ def main():
     # 6. u32 PML: a read longer than 65535 bases
     img = pkg.synth_index(500, mean_len=4, split_permille=0, seed=9)
     long_read = helpers.backward_walk_reads(img, 1, 66000, 0.0005, seed=10)
-    check(img, long_read + rand_reads(rng, 3, 1, 30), "wide_pml", wide=True)
+    check(img, long_read + rand_reads(rng, 3, 1, 30), "wide_pml", wide=True, extra_layouts=())
+    short = [long_read[0][-900:]] + rand_reads(rng, 3, 1, 30)             # the u32 kernels of the line rows, small
+    check(img, short, "wide_pml_line_rows", wide=True)
     try:
         bases, off = helpers.concat_reads(long_read)
         pkg.ColPml.from_bytes(bytes(img)).query_batch(bases, off, wide=False)
@@ -209,7 +215,7 @@ def main():
     #    holds the one-step tables)
     img = pkg.synth_index(1200, mean_len=6, split_permille=80, seed=31)
     got = []
-    for layout in (1, 2, 3):
+    for layout in (1, 2, 3, 4):
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         b = np.zeros(300 * 90 + 64, np.uint8)
         o = np.zeros(301, np.uint64)
@@ -217,8 +223,8 @@ def main():
         got.append(b[:300 * 90].copy())
         assert np.array_equal(o, np.arange(301, dtype=np.uint64) * 90)
         tbl.close()
-    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
-    print("ok sampler: identical reads from layouts 1, 2, 3")
+    assert all(np.array_equal(got[0], x) for x in got[1:])
+    print("ok sampler: identical reads from layouts 1, 2, 3, 4")
 
     # 9. HBM budget (COLBWT_HBM_BUDGET_MB): AUTO falls back to the deepest layout that fits; an
     #    explicit layout that does not fit is COLBWT_ERR_NOMEM; nothing is left allocated
@@ -227,12 +233,13 @@ def main():
     bases, off = helpers.concat_reads(reads)
     epml, ecid = oracle.OracleIndex(bytes(img)).query_batch(bases, off)
     full = {}
-    for layout in (1, 2, 3):
+    for layout in (1, 2, 3, 4):
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         full[layout] = tbl.info().device_bytes
         tbl.close()
-    assert full[1] < full[2] < full[3]
-    for budget_mb, expect in ((10_000, 3), (full[3] / 2**20 - 0.01, 2), (full[2] / 2**20 - 0.01, 1)):
+    assert full[1] < full[2] < full[3] < full[4]
+    for budget_mb, expect in ((10_000, 4), (full[4] / 2**20 - 0.01, 3), (full[3] / 2**20 - 0.01, 2),
+                              (full[2] / 2**20 - 0.01, 1)):
         os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)
         tbl = pkg.ColPml.from_bytes(img, layout=0)
         assert tbl.info().layout == expect, (budget_mb, tbl.info().layout, full)

@@ -4,9 +4,9 @@ failure paths the capacity configuration depends on.
   C3  the per-rank shard of the 8-GPU run is the C2 batch (same index, 10 M x 150 bp per GPU):
       covered by test_gpu_parity.py::test_full_scale_properties and named here.
   C4  2e8-row index, >= 100 k reads of ~10 kbp (+-20 % length jitter, 5 % substitutions), all
-      three HBM layouts, device entry point with and without the length order, host entry point.
-  C5  capacity: the largest indices one MI355X takes -- 1e9 rows opened with AUTO (three-step
-      rows, ~130 GB resident), 1.7e9 rows where the three-step refinement passes 2^32-2 rows and
+      four HBM layouts, device entry point with and without the length order, host entry point.
+  C5  capacity: the largest indices one MI355X takes -- 1e9 rows opened with AUTO (line rows do
+      not fit: three-step rows, ~130 GB resident), 1.7e9 rows where the three-step refinement passes 2^32-2 rows and
       AUTO must settle for two-step rows -- plus the HBM-budget fallback and what a failed open
       leaves behind.
 Sizes shrink with COLBWT_TEST_ROWS / COLBWT_TEST_BIG_ROWS for rehearsals.
@@ -72,7 +72,7 @@ def test_c4_long_reads_all_layouts(pkg, oracle, c2_image):
     ref = oracle.OracleIndex(c2_image)
     expect = None
     host_result = None
-    for layout in (3, 2, 1):
+    for layout in (4, 3, 2, 1):
         _free_hbm()
         tbl = pkg.ColPml.from_bytes(c2_image, layout=layout)
         assert tbl.info().layout == layout
@@ -182,11 +182,18 @@ def test_hbm_budget_fallback_and_failed_open_leaves_nothing(pkg, oracle, c2_imag
     finally:
         os.environ.pop("COLBWT_HBM_BUDGET_MB", None)
     assert base - _free_hbm() < 64 << 20
-    tbl = pkg.ColPml.from_bytes(c2_image, layout=0)
+    tbl = pkg.ColPml.from_bytes(c2_image, layout=3)
     info = tbl.info()
-    assert info.layout == 3
     if C2_ROWS == 200_000_000:
         assert 24e9 < info.device_bytes < 27e9, info.device_bytes     # 31.9 GB with the one-step tables kept
+    tbl.close()
+    assert base - _free_hbm() < 64 << 20
+    tbl = pkg.ColPml.from_bytes(c2_image, layout=0)                  # no budget: AUTO = line rows, 8 look-ahead steps
+    info = tbl.info()
+    assert info.layout == 4 and info.layout_shape == (8 << 8 | 2)
+    if C2_ROWS == 200_000_000:
+        assert 0.9e9 < info.table_rows < 1.2e9 and 140e9 < info.device_bytes < 170e9, (info.table_rows, info.device_bytes)
+    _oracle_sample_check(pkg, ref, tbl, 200_000, 150, 9, 20_000)
     tbl.close()
     assert base - _free_hbm() < 64 << 20
 

@@ -18,6 +18,10 @@ import helpers
 
 pytestmark = pytest.mark.gpu
 
+# HBM layouts every parity case runs on (include/colbwt.h): 1 = one-step, 2 / 3 = K-step rows,
+# 4 = line rows with the default number of look-ahead steps and with two more (steps << 8)
+LAYOUTS = (1, 2, 3, 4, 4 | (5 << 8), 4 | (4 << 8))
+
 
 def _loaded_hip_lib(pkg):
     path = pkg.LIB_PATH
@@ -30,9 +34,9 @@ def _check(pkg, oracle, image, reads, wide=False):
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
     epml, ecid = ref.query_batch(bases, off, wide=wide, threads=8)
-    for layout in (1, 2, 3):  # one-step rows and K-step refined rows must all be bit-exact
+    for layout in LAYOUTS:  # one-step rows, K-step refined rows and line rows must all be bit-exact
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
-        assert tbl.info().layout == layout
+        assert tbl.info().layout == layout & 0xFF
         pml, cid, st = tbl.query_batch(bases, off, wide=wide)
         assert np.array_equal(pml, epml), f"layout {layout}: PML differs at {np.flatnonzero(pml != epml)[:8]}"
         assert np.array_equal(cid, ecid), f"layout {layout}: col-id differs at {np.flatnonzero(cid != ecid)[:8]}"
@@ -253,7 +257,7 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
     assert 0.02 < resets < 0.6          # the recipe's mix of extends and resets
 
 
-@pytest.mark.parametrize("layout", [1, 2, 3])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4])
 def test_full_scale_properties(pkg, oracle, layout, c2_image):
     """BASELINE config C2 scale (2e8 rows): size-independent properties --
     idempotence (two runs, identical bytes), batch-position independence (a
@@ -366,7 +370,7 @@ def test_open_close_does_not_leak_hbm(pkg):
     image = pkg.synth_index(1_000_000, mean_len=8, split_permille=0, seed=5)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(0)[0]
-    for layout in (1, 2, 3, 0) * 3:
+    for layout in (1, 2, 3, 4, 0) * 2:
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
         assert tbl.info().device_bytes > 0
         tbl.close()

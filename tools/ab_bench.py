@@ -56,11 +56,15 @@ def main():
     d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
     d_off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
     variants = []
+    def layout_arg(lay):                     # "3", or "4:6" = line rows with K = 6 look-ahead steps
+        kind, _, steps = lay.partition(":")
+        return int(kind or 0) | (int(steps) << 8 if steps else 0)
+
     for spec in a.libs:                      # "lib.so" or "lib.so@2" (HBM table layout)
         path, _, lay = spec.partition("@")
         L = bind(os.path.abspath(path))
         h = C.c_void_p()
-        rc = L.colbwt_index_open_memory_layout(image.ctypes.data, image.size, None, 0, int(lay or 0), C.byref(h))
+        rc = L.colbwt_index_open_memory_layout(image.ctypes.data, image.size, None, 0, layout_arg(lay), C.byref(h))
         assert rc == 0, L.colbwt_last_error()
         variants.append((os.path.basename(spec), L, h, []))
     name0, L0, h0, _ = variants[0]
