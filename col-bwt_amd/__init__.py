@@ -22,8 +22,10 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "colbwt.h")
 EXPORTS = (
     "colbwt_version", "colbwt_last_error", "colbwt_index_open", "colbwt_index_open_memory",
     "colbwt_index_open_layout", "colbwt_index_open_memory_layout",
+    "colbwt_index_open_devices", "colbwt_index_open_memory_devices",
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
-    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
+    "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_query_file_binary",
+    "colbwt_binary_to_text", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
 )
 
@@ -37,7 +39,8 @@ class ColbwtError(RuntimeError):
 class Info(C.Structure):
     _fields_ = [("bwt_r", C.c_uint64), ("n", C.c_uint64), ("r", C.c_uint64), ("sigma", C.c_uint32),
                 ("device", C.c_uint32), ("device_bytes", C.c_uint64), ("layout", C.c_uint32),
-                ("layout_shape", C.c_uint32), ("table_rows", C.c_uint64)]
+                ("layout_shape", C.c_uint32), ("table_rows", C.c_uint64), ("n_devices", C.c_uint32),
+                ("reserved_", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -75,6 +78,8 @@ def lib():
     L.colbwt_index_open_memory.argtypes = [vp, u64, vp, i32, C.POINTER(vp)]
     L.colbwt_index_open_layout.argtypes = [C.c_char_p, vp, i32, i32, C.POINTER(vp)]
     L.colbwt_index_open_memory_layout.argtypes = [vp, u64, vp, i32, i32, C.POINTER(vp)]
+    L.colbwt_index_open_devices.argtypes = [C.c_char_p, vp, C.POINTER(i32), i32, i32, C.POINTER(vp)]
+    L.colbwt_index_open_memory_devices.argtypes = [vp, u64, vp, C.POINTER(i32), i32, i32, C.POINTER(vp)]
     L.colbwt_index_close.argtypes = [vp]
     L.colbwt_index_close.restype = None
     L.colbwt_index_info.argtypes = [vp, C.POINTER(Info)]
@@ -83,6 +88,8 @@ def lib():
     L.colbwt_query_device.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, C.POINTER(Stats)]
     L.colbwt_query_device_ordered.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp, vp, vp, C.POINTER(Stats)]
     L.colbwt_query_file.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.POINTER(Stats)]
+    L.colbwt_query_file_binary.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.POINTER(Stats)]
+    L.colbwt_binary_to_text.argtypes = [C.c_char_p, i32, C.c_char_p]
     L.colbwt_synth_index_bytes.argtypes = [u64]
     L.colbwt_synth_index_bytes.restype = u64
     L.colbwt_synth_index.argtypes = [u64, C.c_uint32, C.c_uint32, u64, vp, u64]
@@ -117,19 +124,30 @@ class ColPml:
         self._h = handle
 
     @classmethod
-    def load(cls, prefix_or_file, device=0, layout=0):
-        """layout: 0 = engine default, 1 = one-step rows, 2 / 3 = K-step rows (same results)."""
+    def load(cls, prefix_or_file, device=0, layout=0, devices=None):
+        """layout: 0 = engine default, 1 = one-step rows, 2 / 3 = K-step rows, 4 = line rows (same results)."""
         h = C.c_void_p()
-        _check(lib().colbwt_index_open_layout(os.fsencode(prefix_or_file), None, int(device), int(layout),
-                                              C.byref(h)))
+        if devices is not None:
+            dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib().colbwt_index_open_devices(os.fsencode(prefix_or_file), None, dv, len(devices), int(layout),
+                                                   C.byref(h)))
+        else:
+            _check(lib().colbwt_index_open_layout(os.fsencode(prefix_or_file), None, int(device), int(layout),
+                                                  C.byref(h)))
         return cls(h)
 
     @classmethod
-    def from_bytes(cls, image, device=0, layout=0):
+    def from_bytes(cls, image, device=0, layout=0, devices=None):
+        """devices: a list of device ordinals (one replica each; a device may repeat) instead of `device`."""
         arr = np.ascontiguousarray(np.frombuffer(image, dtype=np.uint8))
         h = C.c_void_p()
-        _check(lib().colbwt_index_open_memory_layout(arr.ctypes.data, arr.size, None, int(device), int(layout),
-                                                     C.byref(h)))
+        if devices is not None:
+            dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib().colbwt_index_open_memory_devices(arr.ctypes.data, arr.size, None, dv, len(devices), int(layout),
+                                                          C.byref(h)))
+        else:
+            _check(lib().colbwt_index_open_memory_layout(arr.ctypes.data, arr.size, None, int(device), int(layout),
+                                                         C.byref(h)))
         return cls(h)
 
     def info(self):
@@ -178,6 +196,15 @@ class ColPml:
                                        batch_bases, C.byref(st)))
         return st
 
+    def query_file_binary(self, pattern_path, pml_bin_path=None, cid_bin_path=None, batch_bases=0):
+        """`col-bwt query`'s binary outputs (<pattern>.pml.bin / .cid.bin; Movi-like container, unverified)."""
+        st = Stats()
+        _check(lib().colbwt_query_file_binary(self._h, os.fsencode(pattern_path),
+                                              os.fsencode(pml_bin_path) if pml_bin_path else None,
+                                              os.fsencode(cid_bin_path) if cid_bin_path else None,
+                                              batch_bases, C.byref(st)))
+        return st
+
     def synth_reads_device(self, n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream=0):
         _check(lib().colbwt_synth_reads_device(self._h, n_reads, read_len, sub_permille, seed,
                                                d_bases, d_read_off, stream))
@@ -192,6 +219,26 @@ class ColPml:
             self.close()
         except Exception:
             pass
+
+
+def binary_to_text(bin_path, value_bytes, text_path):
+    """Container -> reference text (`col-bwt view`); value_bytes 2 = .pml.bin, 1 = .cid.bin."""
+    _check(lib().colbwt_binary_to_text(os.fsencode(bin_path), int(value_bytes), os.fsencode(text_path)))
+
+
+def read_binary(bin_path, value_bytes):
+    """Parses a container: [(name, values in pattern order as a numpy array)]."""
+    raw = np.fromfile(bin_path, dtype=np.uint8)
+    out, at = [], 0
+    dt = np.uint16 if value_bytes == 2 else np.uint8
+    while at < raw.size:
+        nl = int(raw[at:at + 2].view(np.uint16)[0])
+        name = raw[at + 2:at + 2 + nl].tobytes().decode()
+        m = int(raw[at + 2 + nl:at + 10 + nl].view(np.uint64)[0])
+        at += 10 + nl
+        out.append((name, raw[at:at + m * value_bytes].view(dt)[::-1].copy()))
+        at += m * value_bytes
+    return out
 
 
 def pml_pack_device(d_pml, n_bases, d_mask, stream=0):

@@ -21,6 +21,8 @@
 #include <vector>
 
 #include "../../include/colbwt.h"
+#include "bin_writer.h"
+#include "fasta_parallel.h"
 #include "fastx_reader.h"
 #include "index.h"
 #include "query_kernels.h"
@@ -31,8 +33,56 @@ using namespace colbwt;
 #define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_LINE_ROWS
 constexpr int kDefaultLineSteps = 8;
 
+// Device buffers, stream and events of one host-entry query, kept with the handle between calls
+// (a file query makes one call per 64 Mbase batch: four hipMalloc / hipFree pairs, a stream and
+// four events per call otherwise).  One caller at a time holds it; concurrent callers on the
+// same replica work with a set of their own that lives for the call.
+struct BatchScratch {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // bases, offsets, pml, cid, order
+    size_t cap[5] = {0, 0, 0, 0, 0};
+    ~BatchScratch() { release(); }
+    void release() {
+        for (int k = 0; k < 5; ++k) {
+            if (buf[k]) (void)hipFree(buf[k]);
+            buf[k] = nullptr;
+            cap[k] = 0;
+        }
+        for (auto &e : ev) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+    hipError_t ready() {   // stream + events exist
+        hipError_t e = hipSuccess;
+        if (!stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        for (auto &x : ev)
+            if (e == hipSuccess && !x) e = hipEventCreate(&x);
+        return e;
+    }
+    hipError_t need(int k, size_t bytes) {   // buf[k] holds at least `bytes` (grown with headroom)
+        if (bytes <= cap[k]) return hipSuccess;
+        if (buf[k]) (void)hipFree(buf[k]);
+        buf[k] = nullptr;
+        cap[k] = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        const hipError_t e = hipMalloc(&buf[k], want);
+        if (e == hipSuccess) cap[k] = want;
+        return e;
+    }
+};
+
 struct colbwt_index {
     Index ix;
+    // Further replicas of the table, one per extra device (colbwt_index_open_devices): each is a
+    // handle of its own kind, owned by this one.  The host entry points shard a batch over
+    // [this] + more; the device entry points address the replica on the buffers' device.
+    std::vector<colbwt_index *> more;
+    std::mutex scratch_mu;
+    BatchScratch scratch;
     // Two pinned staging buffers for results that go to pageable host memory (kept for the
     // life of the handle: pinning costs as much as a copy).  One caller at a time uses them;
     // concurrent callers fall back to the runtime's own pageable copy.
@@ -40,6 +90,9 @@ struct colbwt_index {
     void *stage[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
     ~colbwt_index() {
+        for (colbwt_index *r : more) delete r;
+        if (ix.device() >= 0) (void)hipSetDevice(ix.device());
+        scratch.release();
         for (void *p : stage)
             if (p) (void)hipHostFree(p);
     }
@@ -177,9 +230,134 @@ hipError_t staged_d2h(colbwt_index *idx, const D2HSegment *seg, int n_seg, hipSt
     return e != hipSuccess ? e : e2;
 }
 
+// One replica's part of a host-entry query: reads [0, n_reads) of `read_off`, whose offsets are
+// relative to `bases` after subtracting `off0` (a shard of a larger batch keeps the caller's
+// offsets).  Results go to pml / cid indexed like `bases`.
 template <typename PmlT>
-int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, PmlT *pml,
-                     uint8_t *cid, colbwt_stats *stats) {
+int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t off0, uint64_t n_reads,
+                     PmlT *pml, uint8_t *cid, uint64_t max_len, uint64_t min_len, colbwt_stats *stats, std::string &errmsg) {
+    auto bad = [&](int code, const std::string &m) { errmsg = m; return code; };
+    const uint64_t n_bases = read_off[n_reads] - off0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n_bases == 0) {
+        if (stats) stats->n_reads = n_reads;
+        return COLBWT_OK;
+    }
+    int rc = select_device(idx->ix.device(), errmsg);
+    if (rc != COLBWT_OK) return rc;
+
+    // the handle's scratch when nobody else holds it, else one for this call
+    std::unique_lock<std::mutex> lease(idx->scratch_mu, std::defer_lock);
+    BatchScratch own;
+    BatchScratch &S = lease.try_lock() ? idx->scratch : own;
+
+    // Ragged batch: assign lanes by decreasing read length (counting sort over 256 length
+    // classes is enough: waves only need reads of SIMILAR length side by side).  The line-row
+    // kernel balances by itself (persistent lanes claim chunks of reads).
+    std::vector<uint32_t> order;
+    if (idx->ix.layout() != COLBWT_LAYOUT_LINE_ROWS && n_reads <= 0xFFFFFFFFull && n_reads > 64 &&
+        max_len > min_len + (min_len >> 2) + 16) {
+        const uint64_t span = max_len - min_len + 1;
+        uint32_t shift = 0;
+        while ((span >> shift) > 4096) ++shift;
+        std::vector<uint64_t> start((span >> shift) + 2, 0);
+        for (uint64_t k = 0; k < n_reads; ++k) ++start[((max_len - (read_off[k + 1] - read_off[k])) >> shift) + 1];
+        for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+        order.resize(n_reads);
+        for (uint64_t k = 0; k < n_reads; ++k)
+            order[start[(max_len - (read_off[k + 1] - read_off[k])) >> shift]++] = (uint32_t)k;
+    }
+    std::vector<uint64_t> rebased;                            // offsets from 0 for this shard
+    const uint64_t *off_src = read_off;
+    if (off0 != 0) {
+        rebased.resize(n_reads + 1);
+        for (uint64_t k = 0; k <= n_reads; ++k) rebased[k] = read_off[k] - off0;
+        off_src = rebased.data();
+    }
+    const uint64_t bases_alloc = (n_bases + 64 + 63) & ~63ull;  // the kernel reads whole 64-byte blocks
+    float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
+    uint8_t *d_bases = nullptr, *d_cid = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_order = nullptr;
+    PmlT *d_pml = nullptr;
+    hipStream_t stream = nullptr;
+#define HOST_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError();                                                            \
+            return bad(e_ == hipErrorOutOfMemory ? COLBWT_ERR_NOMEM : COLBWT_ERR_HIP,           \
+                       std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+        }                                                                                       \
+    } while (0)
+    HOST_HIP(S.ready());
+    HOST_HIP(S.need(0, bases_alloc));
+    HOST_HIP(S.need(1, (n_reads + 1) * sizeof(uint64_t)));
+    HOST_HIP(S.need(2, ((n_bases + 15) & ~15ull) * sizeof(PmlT)));
+    HOST_HIP(S.need(3, (n_bases + 15) & ~15ull));
+    if (!order.empty()) HOST_HIP(S.need(4, n_reads * sizeof(uint32_t)));
+    stream = S.stream;
+    d_bases = (uint8_t *)S.buf[0];
+    d_off = (uint64_t *)S.buf[1];
+    d_pml = (PmlT *)S.buf[2];
+    d_cid = (uint8_t *)S.buf[3];
+    d_order = order.empty() ? nullptr : (uint32_t *)S.buf[4];
+
+    HOST_HIP(hipEventRecord(S.ev[0], stream));
+    HOST_HIP(hipMemsetAsync(d_bases + (bases_alloc - 128), 0, 128, stream));
+    HOST_HIP(hipMemcpyAsync(d_bases, bases, n_bases, hipMemcpyHostToDevice, stream));
+    HOST_HIP(hipMemcpyAsync(d_off, off_src, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (d_order) HOST_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HOST_HIP(hipEventRecord(S.ev[1], stream));
+    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+        launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    else if (idx->ix.layout() >= 2)
+        launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    else
+        launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+    HOST_HIP(hipGetLastError());
+    HOST_HIP(hipEventRecord(S.ev[2], stream));
+    {
+        // results into pageable memory go through pinned staging buffers with several copier
+        // threads (the runtime's own pageable path manages ~17 GB/s); pinned destinations and
+        // small batches are copied directly
+        std::unique_lock<std::mutex> stage_lock(idx->stage_mu, std::defer_lock);
+        const bool staged = n_bases * (sizeof(PmlT) + 1) >= kStageMinTotal && is_pageable(pml) && is_pageable(cid) &&
+                            stage_lock.try_lock() && ensure_stage(idx);
+        if (staged) {
+            const D2HSegment seg[2] = {{(uint8_t *)pml, (const uint8_t *)d_pml, n_bases * sizeof(PmlT)},
+                                       {cid, d_cid, n_bases}};
+            HOST_HIP(staged_d2h(idx, seg, 2, stream));
+        } else {
+            HOST_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
+            HOST_HIP(hipMemcpyAsync(cid, d_cid, n_bases, hipMemcpyDeviceToHost, stream));
+        }
+    }
+    HOST_HIP(hipEventRecord(S.ev[3], stream));
+    HOST_HIP(hipStreamSynchronize(stream));
+    HOST_HIP(hipEventElapsedTime(&ms_h2d, S.ev[0], S.ev[1]));
+    HOST_HIP(hipEventElapsedTime(&ms_k, S.ev[1], S.ev[2]));
+    HOST_HIP(hipEventElapsedTime(&ms_d2h, S.ev[2], S.ev[3]));
+#undef HOST_HIP
+    if (stats) {
+        stats->n_reads = n_reads;
+        stats->n_bases = n_bases;
+        stats->h2d_ms = ms_h2d;
+        stats->kernel_ms = ms_k;
+        stats->d2h_ms = ms_d2h;
+        stats->algorithmic_bytes = n_bases * (uint64_t)kAlgBytesPerBase;
+    }
+    return COLBWT_OK;
+}
+
+// col_pml::query_pml for a batch in host memory, over every replica of the handle: the reads are
+// independent (the reference walks them one after the other, pml_query.cpp:74-86), so the batch
+// is cut into contiguous shards of equal base count, one per device, each queried by a host
+// thread of its own on its device's stream and copied straight into its slice of the caller's
+// arrays -- no exchange between devices.
+template <typename PmlT>
+int query_batch_all(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads, PmlT *pml,
+                    uint8_t *cid, colbwt_stats *stats) {
     if (!idx) return fail(COLBWT_ERR_ARG, "null index");
     if (stats) memset(stats, 0, sizeof(*stats));
     if (n_reads == 0) return COLBWT_OK;
@@ -201,96 +379,49 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     }
     if (!bases || !pml || !cid) return fail(COLBWT_ERR_ARG, "null bases/pml/cid");
 
-    int rc = select_device(idx->ix.device(), g_err);
-    if (rc != COLBWT_OK) return rc;
-
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint8_t *d_bases = nullptr, *d_cid = nullptr;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_order = nullptr;
-    PmlT *d_pml = nullptr;
-    // Ragged batch: assign lanes by decreasing read length (counting sort over 256 length
-    // classes is enough: waves only need reads of SIMILAR length side by side).
-    std::vector<uint32_t> order;
-    if (n_reads <= 0xFFFFFFFFull && n_reads > 64 && max_len > min_len + (min_len >> 2) + 16) {
-        const uint64_t span = max_len - min_len + 1;
-        uint32_t shift = 0;
-        while ((span >> shift) > 4096) ++shift;
-        std::vector<uint64_t> start((span >> shift) + 2, 0);
-        for (uint64_t k = 0; k < n_reads; ++k) ++start[((max_len - (read_off[k + 1] - read_off[k])) >> shift) + 1];
-        for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
-        order.resize(n_reads);
-        for (uint64_t k = 0; k < n_reads; ++k)
-            order[start[(max_len - (read_off[k + 1] - read_off[k])) >> shift]++] = (uint32_t)k;
+    std::vector<colbwt_index *> reps{idx};
+    reps.insert(reps.end(), idx->more.begin(), idx->more.end());
+    const size_t R = reps.size();
+    if (R == 1) {
+        std::string msg;
+        const int rc = query_batch_host<PmlT>(idx, bases, read_off, 0, n_reads, pml, cid, max_len, min_len, stats, msg);
+        return rc == COLBWT_OK ? rc : fail(rc, msg);
     }
-    const uint64_t bases_alloc = (n_bases + 64 + 63) & ~63ull;  // the kernel reads whole 64-byte blocks
-    float ms_h2d = 0, ms_k = 0, ms_d2h = 0;
-
-    API_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    for (auto &e : ev) API_HIP(hipEventCreate(&e));
-    API_HIP(hipMalloc((void **)&d_bases, bases_alloc));
-    API_HIP(hipMalloc((void **)&d_off, (n_reads + 1) * sizeof(uint64_t)));
-    API_HIP(hipMalloc((void **)&d_pml, ((n_bases + 15) & ~15ull) * sizeof(PmlT)));
-    API_HIP(hipMalloc((void **)&d_cid, (n_bases + 15) & ~15ull));
-
-    API_HIP(hipEventRecord(ev[0], stream));
-    API_HIP(hipMemsetAsync(d_bases + (bases_alloc - 128), 0, 128, stream));
-    API_HIP(hipMemcpyAsync(d_bases, bases, n_bases, hipMemcpyHostToDevice, stream));
-    API_HIP(hipMemcpyAsync(d_off, read_off, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (!order.empty()) {
-        API_HIP(hipMalloc((void **)&d_order, n_reads * sizeof(uint32_t)));
-        API_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    // shard boundaries by base count (same rule as multi_gpu.shard_reads)
+    std::vector<uint64_t> cut(R + 1, 0);
+    cut[R] = n_reads;
+    for (size_t r = 1; r < R; ++r) {
+        const uint64_t target = n_bases / R * r + n_bases % R * r / R;
+        const uint64_t k = (uint64_t)(std::lower_bound(read_off, read_off + n_reads + 1, target) - read_off);
+        cut[r] = std::min(std::max(k, cut[r - 1]), n_reads);
     }
-    API_HIP(hipEventRecord(ev[1], stream));
-    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
-        launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
-    else if (idx->ix.layout() >= 2)
-        launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
-    else
-        launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
-    API_HIP(hipGetLastError());
-    API_HIP(hipEventRecord(ev[2], stream));
-    {
-        // results into pageable memory go through pinned staging buffers with several copier
-        // threads (the runtime's own pageable path manages ~17 GB/s); pinned destinations and
-        // small batches are copied directly
-        std::unique_lock<std::mutex> stage_lock(idx->stage_mu, std::defer_lock);
-        const bool staged = n_bases * (sizeof(PmlT) + 1) >= kStageMinTotal && is_pageable(pml) && is_pageable(cid) &&
-                            stage_lock.try_lock() && ensure_stage(idx);
-        if (staged) {
-            const D2HSegment seg[2] = {{(uint8_t *)pml, (const uint8_t *)d_pml, n_bases * sizeof(PmlT)},
-                                       {cid, d_cid, n_bases}};
-            API_HIP(staged_d2h(idx, seg, 2, stream));
-        } else {
-            API_HIP(hipMemcpyAsync(pml, d_pml, n_bases * sizeof(PmlT), hipMemcpyDeviceToHost, stream));
-            API_HIP(hipMemcpyAsync(cid, d_cid, n_bases, hipMemcpyDeviceToHost, stream));
+    std::vector<int> rcs(R, COLBWT_OK);
+    std::vector<std::string> msgs(R);
+    std::vector<colbwt_stats> sts(R);
+    auto work = [&](size_t r) {
+        const uint64_t lo = cut[r], hi = cut[r + 1];
+        if (hi == lo) return;
+        const uint64_t off0 = read_off[lo];
+        rcs[r] = query_batch_host<PmlT>(reps[r], bases + off0, read_off + lo, off0, hi - lo, pml + off0, cid + off0, max_len,
+                                        min_len, &sts[r], msgs[r]);
+    };
+    std::vector<std::thread> threads;
+    for (size_t r = 1; r < R; ++r) threads.emplace_back(work, r);
+    work(0);
+    for (auto &t : threads) t.join();
+    for (size_t r = 0; r < R; ++r)
+        if (rcs[r] != COLBWT_OK) return fail(rcs[r], "device " + std::to_string(reps[r]->ix.device()) + ": " + msgs[r]);
+    if (stats) {
+        for (size_t r = 0; r < R; ++r) {
+            stats->n_reads += sts[r].n_reads;
+            stats->n_bases += sts[r].n_bases;
+            stats->algorithmic_bytes += sts[r].algorithmic_bytes;
+            stats->h2d_ms = std::max(stats->h2d_ms, sts[r].h2d_ms);          // the devices work side by side
+            stats->kernel_ms = std::max(stats->kernel_ms, sts[r].kernel_ms);
+            stats->d2h_ms = std::max(stats->d2h_ms, sts[r].d2h_ms);
         }
     }
-    API_HIP(hipEventRecord(ev[3], stream));
-    API_HIP(hipStreamSynchronize(stream));
-    API_HIP(hipEventElapsedTime(&ms_h2d, ev[0], ev[1]));
-    API_HIP(hipEventElapsedTime(&ms_k, ev[1], ev[2]));
-    API_HIP(hipEventElapsedTime(&ms_d2h, ev[2], ev[3]));
-    if (stats) {
-        stats->n_reads = n_reads;
-        stats->n_bases = n_bases;
-        stats->h2d_ms = ms_h2d;
-        stats->kernel_ms = ms_k;
-        stats->d2h_ms = ms_d2h;
-        stats->algorithmic_bytes = n_bases * (uint64_t)kAlgBytesPerBase;
-    }
-    rc = COLBWT_OK;
-done:
-    if (d_bases) (void)hipFree(d_bases);
-    if (d_off) (void)hipFree(d_off);
-    if (d_order) (void)hipFree(d_order);
-    if (d_pml) (void)hipFree(d_pml);
-    if (d_cid) (void)hipFree(d_cid);
-    for (auto &e : ev)
-        if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
-    return rc;
+    return COLBWT_OK;
 }
 
 }  // namespace
@@ -356,9 +487,24 @@ private:
 
 }  // namespace
 
+// The replica of a multi-device handle that lives on the device holding `d_ptr` (the first one
+// when the pointer's device cannot be told or holds no replica).
+static colbwt_index *replica_for(colbwt_index *idx, const void *d_ptr) {
+    if (idx->more.empty()) return idx;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, d_ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return idx;
+    }
+    if (a.device == idx->ix.device()) return idx;
+    for (colbwt_index *r : idx->more)
+        if (r->ix.device() == a.device) return r;
+    return idx;
+}
+
 extern "C" {
 
-const char *colbwt_version(void) { return "colbwt-mi355x 0.1.0 (gfx950)"; }
+const char *colbwt_version(void) { return "colbwt-mi355x 0.2.0 (gfx950)"; }
 
 const char *colbwt_last_error(void) { return g_err.c_str(); }
 
@@ -436,6 +582,49 @@ int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *wi
     return colbwt_index_open_memory_layout(mf.data, mf.len, widths, device, layout, out);
 }
 
+// The same table on several devices (the replacement's open takes the devices to
+// use): replica k is loaded on devices[k]; every replica ends up with the layout the FIRST one
+// got (AUTO falls back on the first device only, so that all replicas answer from the same kind
+// of table), a device may be listed more than once (two replicas in one HBM).
+int colbwt_index_open_memory_devices(const void *bytes, uint64_t len, const colbwt_widths *widths, const int *devices,
+                                     int n_devices, int layout, colbwt_index **out) {
+    if (!out) return fail(COLBWT_ERR_ARG, "null out");
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) return fail(COLBWT_ERR_ARG, "device list must hold 1 .. 64 devices");
+    colbwt_index *first = nullptr;
+    int rc = colbwt_index_open_memory_layout(bytes, len, widths, devices[0], layout, &first);
+    if (rc != COLBWT_OK) return rc;
+    colbwt_info info;
+    (void)colbwt_index_info(first, &info);
+    const int same = (int)info.layout | (info.layout == COLBWT_LAYOUT_LINE_ROWS ? (int)(info.layout_shape >> 8) << 8 : 0);
+    for (int k = 1; k < n_devices; ++k) {
+        colbwt_index *rep = nullptr;
+        rc = colbwt_index_open_memory_layout(bytes, len, widths, devices[k], same, &rep);
+        if (rc != COLBWT_OK) {
+            const std::string msg = "replica on device " + std::to_string(devices[k]) + ": " + g_err;
+            delete first;
+            return fail(rc, msg);
+        }
+        first->more.push_back(rep);
+    }
+    *out = first;
+    return COLBWT_OK;
+}
+
+int colbwt_index_open_devices(const char *prefix_or_file, const colbwt_widths *widths, const int *devices, int n_devices,
+                              int layout, colbwt_index **out) {
+    if (!prefix_or_file || !out) return fail(COLBWT_ERR_ARG, "null argument");
+    *out = nullptr;
+    MappedFile mf;                                            // pml_query.cpp:110-111, as colbwt_index_open_layout
+    if (!mf.open(std::string(prefix_or_file) + ".col_pml")) {
+        MappedFile direct;
+        if (!direct.open(prefix_or_file))
+            return fail(COLBWT_ERR_IO, std::string("cannot open ") + prefix_or_file + ".col_pml (or " + prefix_or_file + ")");
+        return colbwt_index_open_memory_devices(direct.data, direct.len, widths, devices, n_devices, layout, out);
+    }
+    return colbwt_index_open_memory_devices(mf.data, mf.len, widths, devices, n_devices, layout, out);
+}
+
 void colbwt_index_close(colbwt_index *idx) { delete idx; }
 
 int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
@@ -451,17 +640,19 @@ int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
                             ? (idx->ix.table_fat().steps << 8) | kFatSlotSteps
                             : 0;
     out->table_rows = idx->ix.table_rows();
+    out->n_devices = 1 + (uint32_t)idx->more.size();
+    out->reserved_ = 0;
     return COLBWT_OK;
 }
 
 int colbwt_query_batch(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                        uint16_t *pml, uint8_t *cid, colbwt_stats *stats) {
-    return query_batch_host<uint16_t>(idx, bases, read_off, n_reads, pml, cid, stats);
+    return query_batch_all<uint16_t>(idx, bases, read_off, n_reads, pml, cid, stats);
 }
 
 int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
                            uint32_t *pml, uint8_t *cid, colbwt_stats *stats) {
-    return query_batch_host<uint32_t>(idx, bases, read_off, n_reads, pml, cid, stats);
+    return query_batch_all<uint32_t>(idx, bases, read_off, n_reads, pml, cid, stats);
 }
 
 int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
@@ -481,6 +672,7 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
     if (!d_bases || !d_read_off || !d_pml || !d_cid) return fail(COLBWT_ERR_ARG, "null device pointer");
     if (((uintptr_t)d_bases & 15) || ((uintptr_t)d_pml & 31) || ((uintptr_t)d_cid & 15))
         return fail(COLBWT_ERR_ARG, "d_bases/d_cid must be 16-byte aligned and d_pml 32-byte aligned");
+    idx = replica_for(idx, d_bases);
     int rc = select_device(idx->ix.device(), g_err);
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -515,32 +707,36 @@ done:
 }
 
 // pml_query vec mode (pml_query.cpp:92-143) as a three-stage pipeline over batches of reads:
-// a reader thread parses the FASTA/FASTQ (kseq semantics), the calling thread runs the GPU
-// query, a writer thread formats and writes the two text files -- so the wall time is the
-// slowest stage's, not the sum.  Output bytes and order are those of the sequential loop.
-int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path, const char *cid_path,
-                      uint64_t batch_bases, colbwt_stats *stats) {
-    if (!idx || !pattern_path) return fail(COLBWT_ERR_ARG, "null argument");
+// a reader thread parses the FASTA/FASTQ (kseq semantics; a plain FASTA by several threads),
+// the calling thread runs the GPU query (on every replica of the handle), a writer thread lays
+// out and writes the two result files -- so the wall time is the slowest stage's, not the sum.
+// Output bytes and order are those of the sequential loop.  `binary`: the container of
+// bin_writer.h instead of the reference's text.
+static int query_file_impl(colbwt_index *idx, const char *pattern_path, const std::string &pml_name,
+                           const std::string &cid_name, uint64_t batch_bases, colbwt_stats *stats, bool binary) {
     if (stats) memset(stats, 0, sizeof(*stats));
-    if (batch_bases == 0) batch_bases = 64ull << 20;
-    // pml_query.cpp:124-125
-    const std::string pml_name = pml_path ? pml_path : std::string(pattern_path) + ".pml";
-    const std::string cid_name = cid_path ? cid_path : std::string(pattern_path) + ".cid";
+    const size_t replicas = 1 + idx->more.size();
+    if (batch_bases == 0) batch_bases = (64ull << 20) * replicas;
+    ParallelFasta fasta;
     FastxReader reader;
-    if (!reader.open(pattern_path)) return fail(COLBWT_ERR_IO, std::string("cannot open pattern file ") + pattern_path);
+    bool parallel = fasta.open(pattern_path);
+    if (!parallel && !reader.open(pattern_path)) return fail(COLBWT_ERR_IO, std::string("cannot open pattern file ") + pattern_path);
     TextWriter wp, wc;
-    if (!wp.open(pml_name)) return fail(COLBWT_ERR_IO, "cannot create " + pml_name);
-    if (!wc.open(cid_name)) return fail(COLBWT_ERR_IO, "cannot create " + cid_name);
+    BinWriter bp, bc;
+    if (!(binary ? bp.open(pml_name) : wp.open(pml_name))) return fail(COLBWT_ERR_IO, "cannot create " + pml_name);
+    if (!(binary ? bc.open(cid_name) : wc.open(cid_name))) return fail(COLBWT_ERR_IO, "cannot create " + cid_name);
 
     constexpr int kInFlight = 3;
     FileBatch pool[kInFlight];
     BatchQueue free_q, parsed_q, done_q;
     for (auto &b : pool) free_q.push(&b);
     std::atomic<bool> stop{false};   // a later stage failed: the reader stops feeding
+    std::atomic<bool> reader_failed{false};
     const bool trace = getenv("COLBWT_TRACE") != nullptr;
     double t_parse = 0, t_gpu = 0, t_format = 0;   // busy seconds of the three stages
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
+    const unsigned host_threads = std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
 
     std::thread reader_thread([&] {
         bool more = true;
@@ -551,20 +747,34 @@ int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *p
             b->names.clear();
             b->off.assign(1, 0);
             uint64_t max_len = 0;
-            std::string name;
-            while (b->bases.size() < batch_bases) {  // pml_query.cpp:74 while (patterns.read())
-                if (!reader.next(name, b->bases)) {
-                    more = false;
-                    break;
+            if (parallel) {
+                const ParallelFasta::Result r = fasta.next_batch(batch_bases, host_threads / 2, b->names, b->bases, b->off, max_len);
+                if (r == ParallelFasta::kEnd) more = false;
+                if (r == ParallelFasta::kNotPlainFasta) {       // FASTQ-style lines ahead: one record at a time from here
+                    parallel = false;
+                    if (!reader.open_at(pattern_path, fasta.position())) {
+                        reader_failed.store(true);
+                        more = false;
+                    }
                 }
-                b->names.push_back(name);
-                max_len = std::max<uint64_t>(max_len, b->bases.size() - b->off.back());
-                b->off.push_back(b->bases.size());
+            }
+            if (!parallel && more) {
+                std::string name;
+                while (b->bases.size() < batch_bases) {  // pml_query.cpp:74 while (patterns.read())
+                    if (!reader.next(name, b->bases)) {
+                        more = false;
+                        break;
+                    }
+                    b->names.push_back(name);
+                    max_len = std::max<uint64_t>(max_len, b->bases.size() - b->off.back());
+                    b->off.push_back(b->bases.size());
+                }
             }
             b->wide = max_len > 65535;
             t_parse += now() - t0;
             if (b->names.empty()) {
                 free_q.push(b);
+                if (more) continue;
                 break;
             }
             parsed_q.push(b);
@@ -572,19 +782,25 @@ int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *p
         parsed_q.push(nullptr);
     });
 
-    const unsigned fmt_threads = std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
     std::thread writer_thread([&] {
         for (;;) {
             FileBatch *b = done_q.pop();
             if (!b) break;
             const uint64_t n_reads = b->names.size();
             const double t0 = now();
-            // pml_query.cpp:78-85; the two files are formatted side by side, each by several
+            // pml_query.cpp:78-85; the two files are laid out side by side, each by several
             // host threads (same bytes, same order as the sequential loop)
-            std::thread cid_thread(
-                [&] { wc.batch(b->names, b->off.data(), b->cid.as<uint8_t>(), n_reads, fmt_threads / 2); });
-            if (b->wide) wp.batch(b->names, b->off.data(), b->pml.as<uint32_t>(), n_reads, fmt_threads / 2);
-            else wp.batch(b->names, b->off.data(), b->pml.as<uint16_t>(), n_reads, fmt_threads / 2);
+            std::thread cid_thread([&] {
+                if (binary) bc.batch<uint8_t>(b->names, b->off.data(), b->cid.as<uint8_t>(), n_reads, host_threads / 2);
+                else wc.batch(b->names, b->off.data(), b->cid.as<uint8_t>(), n_reads, host_threads / 2);
+            });
+            if (binary) {
+                if (b->wide) bp.batch<uint16_t>(b->names, b->off.data(), b->pml.as<uint32_t>(), n_reads, host_threads / 2);
+                else bp.batch<uint16_t>(b->names, b->off.data(), b->pml.as<uint16_t>(), n_reads, host_threads / 2);
+            } else {
+                if (b->wide) wp.batch(b->names, b->off.data(), b->pml.as<uint32_t>(), n_reads, host_threads / 2);
+                else wp.batch(b->names, b->off.data(), b->pml.as<uint16_t>(), n_reads, host_threads / 2);
+            }
             cid_thread.join();
             t_format += now() - t0;
             free_q.push(b);
@@ -633,12 +849,35 @@ int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *p
     done_q.push(nullptr);
     reader_thread.join();
     writer_thread.join();
-    const bool okp = wp.close(), okc = wc.close();
+    const bool okp = binary ? bp.close() : wp.close(), okc = binary ? bc.close() : wc.close();
     if (trace)
-        fprintf(stderr, "colbwt_query_file: wall %.3f s; busy: parse %.3f, gpu %.3f, format+write %.3f\n",
+        fprintf(stderr, "colbwt_query_file: wall %.3f s; busy: parse %.3f, gpu %.3f, layout+write %.3f\n",
                 now() - t_begin, t_parse, t_gpu, t_format);
     if (rc != COLBWT_OK) return rc;     // message set by the failing call on this thread
+    if (reader_failed.load()) return fail(COLBWT_ERR_IO, std::string("cannot re-open pattern file ") + pattern_path);
     if (!okp || !okc) return fail(COLBWT_ERR_IO, "short write on " + pml_name + " / " + cid_name);
+    return COLBWT_OK;
+}
+
+int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path, const char *cid_path,
+                      uint64_t batch_bases, colbwt_stats *stats) {
+    if (!idx || !pattern_path) return fail(COLBWT_ERR_ARG, "null argument");
+    // pml_query.cpp:124-125
+    return query_file_impl(idx, pattern_path, pml_path ? pml_path : std::string(pattern_path) + ".pml",
+                           cid_path ? cid_path : std::string(pattern_path) + ".cid", batch_bases, stats, false);
+}
+
+int colbwt_query_file_binary(colbwt_index *idx, const char *pattern_path, const char *pml_bin_path, const char *cid_bin_path,
+                             uint64_t batch_bases, colbwt_stats *stats) {
+    if (!idx || !pattern_path) return fail(COLBWT_ERR_ARG, "null argument");
+    return query_file_impl(idx, pattern_path, pml_bin_path ? pml_bin_path : std::string(pattern_path) + ".pml.bin",
+                           cid_bin_path ? cid_bin_path : std::string(pattern_path) + ".cid.bin", batch_bases, stats, true);
+}
+
+int colbwt_binary_to_text(const char *bin_path, int value_bytes, const char *text_path) {
+    if (!bin_path || !text_path) return fail(COLBWT_ERR_ARG, "null argument");
+    std::string err;
+    if (!binary_to_text(bin_path, value_bytes, text_path, err)) return fail(value_bytes == 1 || value_bytes == 2 ? COLBWT_ERR_IO : COLBWT_ERR_ARG, err);
     return COLBWT_OK;
 }
 
@@ -679,6 +918,7 @@ int colbwt_pml_unpack_device(const uint32_t *d_zero_mask, const uint32_t *d_end_
 int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                               uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, void *hip_stream) {
     if (!idx || !d_bases || !d_read_off || read_len == 0) return fail(COLBWT_ERR_ARG, "bad argument");
+    idx = replica_for(idx, d_bases);
     int rc = select_device(idx->ix.device(), g_err);
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;

@@ -35,6 +35,18 @@ bool FastxReader::open(const std::string &path) {
     return true;
 }
 
+bool FastxReader::open_at(const std::string &path, uint64_t offset) {
+    if (fp_) { gzclose(fp_); fp_ = nullptr; }
+    if (raw_fd_ >= 0) ::close(raw_fd_);
+    raw_fd_ = ::open(path.c_str(), O_RDONLY);
+    if (raw_fd_ < 0 || ::lseek(raw_fd_, (off_t)offset, SEEK_SET) < 0) return false;
+    buf_.resize(4 << 20);
+    begin_ = end_ = 0;
+    eof_ = false;
+    pending_header_ = 0;
+    return true;
+}
+
 int FastxReader::getc_() {
     if (begin_ >= end_) {
         if (eof_) return -1;

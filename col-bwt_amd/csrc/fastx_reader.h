@@ -26,6 +26,8 @@ public:
     FastxReader &operator=(const FastxReader &) = delete;
 
     bool open(const std::string &path);
+    // A plain (non-gzip) file from byte `offset` on, which must be the '>' or '@' of a record.
+    bool open_at(const std::string &path, uint64_t offset);
     // Appends the next record's bases to `bases` and stores its name; false at
     // end of input (or at the first malformed FASTQ record).
     bool next(std::string &name, std::vector<uint8_t> &bases);

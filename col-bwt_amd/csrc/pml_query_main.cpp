@@ -1,12 +1,16 @@
 // pml_query -- drop-in command line of the reference's query executable
 // (src/pml_query.cpp:92-143) over the MI355X engine (libcolbwt.so).
 //
-//   pml_query [-v] [-l] [-d DEVICE] -p <reads.fa|fq[.gz]> <index_prefix>
+//   pml_query [-v] [-l] [-b] [-d DEVICE[,DEVICE..]] -p <reads.fa|fq[.gz]> <index_prefix>
 //
 // Same getopt string as the reference ("rvlN:p:m:s:o:", common.hpp:231; the
-// build-side options are accepted and ignored) plus -d.  Reads
+// build-side options are accepted and ignored) plus -d and -b.  Reads
 // <index_prefix>.col_pml, writes <pattern>.pml and <pattern>.cid in the
 // reference's text format (pml_query.cpp:65-90).
+//   -d 0,1,..  replicates the table on several devices and shards every batch of reads over
+//              them (a device may be listed twice);
+//   -b         writes <pattern>.pml.bin / <pattern>.cid.bin instead (the containers `col-bwt
+//              query` produces; Movi-like, unverified: include/colbwt.h).
 //
 // Deliberate deviations:
 //   * a missing index / pattern argument or an unreadable file is fatal (exit 1);
@@ -20,6 +24,7 @@
 
 #include <chrono>
 #include <string>
+#include <vector>
 
 #include "../../include/colbwt.h"
 
@@ -30,21 +35,29 @@ static double now_s() {
 
 int main(int argc, char *const argv[]) {
     std::string pattern;
-    bool verbose = false;
-    int device = 0;
+    bool verbose = false, binary = false;
+    std::vector<int> devices;
     int c;
-    while ((c = getopt(argc, argv, "rvlN:p:m:s:o:d:")) != -1) {
+    while ((c = getopt(argc, argv, "rvlN:p:m:s:o:d:b")) != -1) {
         switch (c) {
             case 'v': verbose = true; break;
+            case 'b': binary = true; break;
             case 'p': pattern = optarg; break;
-            case 'd': device = atoi(optarg); break;
+            case 'd':
+                for (const char *q = optarg; *q;) {
+                    char *end = nullptr;
+                    devices.push_back((int)strtol(q, &end, 10));
+                    if (end == q) { devices.pop_back(); break; }
+                    q = *end == ',' ? end + 1 : end;
+                }
+                break;
             case 'r': case 'l': case 'N': case 'm': case 's': case 'o': break;
             case '?': printf("ERROR: Unknown option.\n"); break;
         }
     }
     if (argc != optind + 1) {
         fprintf(stderr, "[ERROR]: Invalid number of arguments\n");
-        fprintf(stderr, "usage: pml_query [-v] [-l] [-d device] -p <pattern FASTA/FASTQ[.gz]> <index_prefix>\n");
+        fprintf(stderr, "usage: pml_query [-v] [-l] [-b] [-d device[,device..]] -p <pattern FASTA/FASTQ[.gz]> <index_prefix>\n");
         return 1;
     }
     const std::string prefix = argv[optind];
@@ -55,7 +68,9 @@ int main(int argc, char *const argv[]) {
     const double t_start = now_s();
     printf("[INFO] Loading BWT table supporting LF mapping: \n");
     colbwt_index *idx = nullptr;
-    if (colbwt_index_open(prefix.c_str(), nullptr, device, &idx) != COLBWT_OK) {
+    if (devices.empty()) devices.push_back(0);
+    if (colbwt_index_open_devices(prefix.c_str(), nullptr, devices.data(), (int)devices.size(), COLBWT_LAYOUT_AUTO, &idx) !=
+        COLBWT_OK) {
         fprintf(stderr, "[ERROR]: %s\n", colbwt_last_error());
         return 1;
     }
@@ -66,16 +81,18 @@ int main(int argc, char *const argv[]) {
         printf("[LOG] Number of BWT equal-letter runs: bwt_r = %llu\n", (unsigned long long)info.bwt_r);
         printf("[LOG] Length of complete BWT: n = %llu\n", (unsigned long long)info.n);
         printf("[LOG] Rate n/r = %g\n", (double)info.n / (double)info.r);
-        printf("[LOG] HBM bytes held by the index (device %u): %llu\n", info.device,
-               (unsigned long long)info.device_bytes);
+        printf("[LOG] HBM bytes held by the index (device %u, %u replica%s): %llu each\n", info.device, info.n_devices,
+               info.n_devices == 1 ? "" : "s", (unsigned long long)info.device_bytes);
     }
     const double t_loaded = now_s();
     printf("[INFO] \tLoad Complete\n[INFO] \tElapsed time (s): %.6f\n", t_loaded - t_start);
 
     printf("[INFO] Computing PML Queries: \n");
     colbwt_stats st;
-    const std::string pml_name = pattern + ".pml", cid_name = pattern + ".cid";
-    if (colbwt_query_file(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st) != COLBWT_OK) {
+    const std::string pml_name = pattern + (binary ? ".pml.bin" : ".pml"), cid_name = pattern + (binary ? ".cid.bin" : ".cid");
+    const int qrc = binary ? colbwt_query_file_binary(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st)
+                           : colbwt_query_file(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st);
+    if (qrc != COLBWT_OK) {
         fprintf(stderr, "[ERROR]: %s\n", colbwt_last_error());
         colbwt_index_close(idx);
         return 1;

@@ -62,6 +62,8 @@ typedef struct colbwt_info {
     uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS */
     uint32_t layout_shape; /* line rows: own steps << 8 | steps per mismatch slot; else 0 */
     uint64_t table_rows;   /* rows of the HBM table actually queried   */
+    uint32_t n_devices;    /* replicas of the table (colbwt_index_open_devices); the fields above describe the first */
+    uint32_t reserved_;
 } colbwt_info;
 
 typedef struct colbwt_stats {
@@ -110,6 +112,17 @@ int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *wi
                              colbwt_index **out);
 int colbwt_index_open_memory_layout(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,
                                     int device, int layout, colbwt_index **out);
+/* The table replicated on several devices -- the `device_mask` of SURVEY.md 8(b) as a list, so a
+ * device may appear twice (two replicas in one HBM).  The reference processes its reads one
+ * after the other in one process (pml_query.cpp:74-86); here the host entry points
+ * (colbwt_query_batch[_u32], colbwt_query_file) cut every batch into contiguous shards of equal
+ * base count, one per replica, queried side by side and copied straight into the caller's arrays:
+ * no exchange between devices.  Every replica gets the layout the first one ended up with.  The
+ * device-resident entry points address the replica on the buffers' device. */
+int colbwt_index_open_devices(const char *prefix_or_file, const colbwt_widths *widths, const int *devices,
+                              int n_devices, int layout, colbwt_index **out);
+int colbwt_index_open_memory_devices(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,
+                                     const int *devices, int n_devices, int layout, colbwt_index **out);
 void colbwt_index_close(colbwt_index *idx);
 int colbwt_index_info(const colbwt_index *idx, colbwt_info *out);
 
@@ -153,6 +166,20 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
  * (0 = default). */
 int colbwt_query_file(colbwt_index *idx, const char *pattern_path, const char *pml_path,
                       const char *cid_path, uint64_t batch_bases, colbwt_stats *stats);
+
+/* The same program writing the results as binary containers -- what `col-bwt query` produces
+ * (scripts/col-bwt.py:194-198: PATTERN.split.pml.bin / .split.cid.bin, written there by the
+ * un-vendored Movi fork).  Record shape as SURVEY.md 8(c) recalls it of upstream Movi -- "Movi-like,
+ * UNVERIFIED", parity unpinned: per read  u16 name_len | name | u64 count | count values,
+ * values in computation order (the read's last base first); u16 lengths (saturated at 65535) in
+ * pml_bin_path (NULL => pattern + ".pml.bin"), u8 col ids in cid_bin_path (".cid.bin").  The text
+ * files stay the bit-exact contract; this exists because formatting ~4 text bytes per base
+ * bounds pml_query end to end. */
+int colbwt_query_file_binary(colbwt_index *idx, const char *pattern_path, const char *pml_bin_path,
+                             const char *cid_bin_path, uint64_t batch_bases, colbwt_stats *stats);
+/* Container -> the reference's text (pml_query.cpp:78-85): `col-bwt view`.  value_bytes: 2 for
+ * .pml.bin, 1 for .cid.bin.  Host code. */
+int colbwt_binary_to_text(const char *bin_path, int value_bytes, const char *text_path);
 
 /* ---- index construction (SURVEY.md 8(f) "next" #1) ------------------------ */
 

@@ -22,6 +22,10 @@ import helpers  # noqa: E402
 
 pkg = load_package()
 pkg.LIB_PATH = os.path.join(HERE, "libcolbwt_emu.so")   # emulated build instead of the HIP one
+# opens that leave the layout to the engine use three-step rows here: the emulator runs one OS
+# thread per lane, and the line rows (persistent lanes, eight refinement levels) are exercised by
+# the explicit cases below
+os.environ["COLBWT_LAYOUT"] = "3"
 oracle = load_oracle()
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -89,6 +93,34 @@ def main():
         assert b" 10000 " in open(fa + ".pml", "rb").read()
         tbl.close()
     print("ok big text")
+
+    # 1b'. binary containers and the many-threaded FASTA reader: a file whose tail turns into FASTQ
+    #      (qualities that start with '>'), CRLF line ends; text == oracle, container -> text == text
+    img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=23)
+    rds = helpers.backward_walk_reads(img, 260, 90, 0.02, seed=23) + rand_reads(rng, 80, 0, 130)
+    with tempfile.TemporaryDirectory() as d:
+        mixed = os.path.join(d, "mixed.fx")
+        with open(mixed, "wb") as f:
+            for k, rd in enumerate(rds[:200]):
+                f.write(b">m%d c\r\n" % k + bytes(rd[:40]) + b"\r\n" + bytes(rd[40:]) + b"\r\n")
+            for k, rd in enumerate(rds[200:]):
+                f.write(b"@q%d\n" % k + bytes(rd) + b"\n+\n" + b">" * len(rd) + b"\n")
+        tbl = pkg.ColPml.from_bytes(img)
+        tbl.query_file(mixed, batch_bases=6000)
+        tbl.query_file_binary(mixed, batch_bases=6000)
+        oracle.OracleIndex(bytes(img)).pml_query_files(mixed, mixed + ".opml", mixed + ".ocid")
+        for ext, width in (("pml", 2), ("cid", 1)):
+            text = open(f"{mixed}.{ext}", "rb").read()
+            assert text == open(f"{mixed}.o{ext}", "rb").read(), ext
+            pkg.binary_to_text(f"{mixed}.{ext}.bin", width, f"{mixed}.{ext}.view")
+            assert open(f"{mixed}.{ext}.view", "rb").read() == text, ext
+        two = pkg.ColPml.from_bytes(img, devices=[0, 0])       # two replicas: every batch in two shards
+        assert two.info().n_devices == 2
+        two.query_file(mixed, mixed + ".pml2", mixed + ".cid2", batch_bases=6000)
+        assert open(mixed + ".pml2", "rb").read() == open(mixed + ".pml", "rb").read()
+        assert open(mixed + ".cid2", "rb").read() == open(mixed + ".cid", "rb").read()
+        tbl.close(), two.close()
+    print("ok binary containers, FASTA -> FASTQ hand-over, two replicas")
 
     # 1c. gather codec (multi-GPU exchange step): PML values <-> one bit per base
     def aligned(n, dt):
@@ -238,6 +270,7 @@ def main():
         full[layout] = tbl.info().device_bytes
         tbl.close()
     assert full[1] < full[2] < full[3] < full[4]
+    del os.environ["COLBWT_LAYOUT"]                   # the engine's own choice from here on
     for budget_mb, expect in ((10_000, 4), (full[4] / 2**20 - 0.01, 3), (full[3] / 2**20 - 0.01, 2),
                               (full[2] / 2**20 - 0.01, 1)):
         os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)

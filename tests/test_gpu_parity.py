@@ -507,3 +507,126 @@ def test_host_entry_large_batch_uses_staged_copy(pkg):
         assert np.array_equal(pml.view(np.int16), d_pml[:nb].cpu().numpy())
         assert np.array_equal(cid, d_cid[:nb].cpu().numpy())
     tbl.close()
+
+
+def test_two_replicas_shard_every_batch(pkg, oracle, tmp_path):
+    """colbwt_index_open_devices with the device list [0, 0] (SURVEY.md 8(b) `device_mask`): two
+    replicas of the table on the one GPU, every host batch cut into two shards by base count and
+    queried side by side -- bit-equal to the single-replica result and to the oracle, through
+    colbwt_query_batch, colbwt_query_batch_u32, colbwt_query_file (text and binary) and the
+    `pml_query -d 0,0` command line.  More than one GPU: unmeasured here."""
+    import subprocess
+    rng = np.random.default_rng(91)
+    image = pkg.synth_index(150_000, mean_len=7, split_permille=60, seed=91)
+    reads = helpers.backward_walk_reads(image.tobytes(), 3000, 150, 0.02, seed=92) + _rand_reads(rng, 1500, 0, 300)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    bases, off = helpers.concat_reads(reads)
+    ep, ec = oracle.OracleIndex(image.tobytes()).query_batch(bases, off, threads=8)
+    one = pkg.ColPml.from_bytes(image)
+    two = pkg.ColPml.from_bytes(image, devices=[0, 0])
+    assert one.info().n_devices == 1 and two.info().n_devices == 2 and two.info().layout == one.info().layout
+    for tbl in (one, two):
+        p, c, st = tbl.query_batch(bases, off)
+        assert st.n_reads == len(reads) and st.n_bases == off[-1]
+        assert np.array_equal(p, ep) and np.array_equal(c, ec)
+        p32, c32, _ = tbl.query_batch(bases, off, wide=True)
+        assert np.array_equal(p32, ep.astype(np.uint32)) and np.array_equal(c32, ec)
+    # degenerate shards: fewer reads than replicas, all bases in one read
+    for sub in ([reads[0]], [np.zeros(0, np.uint8), reads[1]], []):
+        b1, o1 = helpers.concat_reads(sub)
+        a = one.query_batch(b1, o1)
+        b = two.query_batch(b1, o1)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    fa = tmp_path / "reads.fa"
+    helpers.write_fasta(fa, reads, width=80)
+    two.query_file(str(fa), batch_bases=100_000)
+    oracle.OracleIndex(image.tobytes()).pml_query_files(str(fa), str(fa) + ".opml", str(fa) + ".ocid")
+    for ext in ("pml", "cid"):
+        assert open(f"{fa}.{ext}", "rb").read() == open(f"{fa}.o{ext}", "rb").read()
+    one.close(), two.close()
+    # the command line with a device list (and -l, which the reference only honours for one read:
+    # col_bwt.hpp:477-495 -- here it writes the normal files, DESIGN.md section 7)
+    idx_file = tmp_path / "tbl.col_pml"
+    idx_file.write_bytes(image.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["-d", "0,0"], ["-l"]):
+        fa2 = tmp_path / ("cli" + "".join(extra).replace(",", "_") + ".fa")
+        shutil.copy(fa, fa2)
+        out = subprocess.run([os.path.join(root, "col-bwt_amd", "pml_query"), "-v"] + extra + ["-p", str(fa2), str(tmp_path / "tbl")],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        if extra[0] == "-d":
+            assert "2 replicas" in out.stdout
+        for ext in ("pml", "cid"):
+            assert open(f"{fa2}.{ext}", "rb").read() == open(f"{fa}.o{ext}", "rb").read()
+
+
+def test_binary_containers_round_trip(pkg, oracle, tmp_path):
+    """`.pml.bin` / `.cid.bin` (include/colbwt.h: Movi-like record shape, unverified against Movi --
+    the reference names these outputs, scripts/col-bwt.py:194, but their writer is not in its
+    tree): values read back from the containers == the text files' values == the oracle's, and
+    `col-bwt view` / colbwt_binary_to_text reproduce the reference's text byte for byte.  FASTA
+    (parsed by several threads), a FASTA whose tail turns into FASTQ (the parallel reader hands
+    over to the sequential one), CRLF line ends, gzip."""
+    import gzip
+    import subprocess
+    import sys
+    rng = np.random.default_rng(95)
+    image = pkg.synth_index(60_000, mean_len=6, split_permille=80, seed=95)
+    reads = helpers.backward_walk_reads(image.tobytes(), 2500, 120, 0.02, seed=96) + _rand_reads(rng, 700, 0, 260)
+    names = [f"rd{k}.{k % 7}" for k in range(len(reads))]
+    ref = oracle.OracleIndex(image.tobytes())
+    tbl = pkg.ColPml.from_bytes(image)
+    plain = tmp_path / "plain.fa"
+    helpers.write_fasta(plain, reads, [nm + " some comment" for nm in names], width=50)
+    crlf = tmp_path / "crlf.fa"
+    with open(crlf, "wb") as f:
+        for nm, rd in zip(names, reads):
+            f.write(b">" + nm.encode() + b"\r\n")
+            for s in range(0, len(rd), 61):
+                f.write(bytes(rd[s:s + 61]) + b"\r\n")
+            f.write(b"\r\n")
+    mixed = tmp_path / "mixed.fx"                            # FASTA records, then FASTQ records
+    with open(mixed, "wb") as f:
+        for nm, rd in list(zip(names, reads))[:1500]:
+            f.write(b">" + nm.encode() + b"\n" + bytes(rd) + b"\n")
+        for nm, rd in list(zip(names, reads))[1500:]:
+            f.write(b"@" + nm.encode() + b"\n" + bytes(rd) + b"\n+\n" + b">" * len(rd) + b"\n")   # qualities of '>'
+    gz = tmp_path / "plain.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(open(plain, "rb").read())
+    for path in (plain, crlf, mixed, gz):
+        tbl.query_file(str(path), batch_bases=40_000)                      # many batches
+        tbl.query_file_binary(str(path), batch_bases=40_000)
+        ref.pml_query_files(str(path), str(path) + ".opml", str(path) + ".ocid")
+        for ext, width in (("pml", 2), ("cid", 1)):
+            text = open(f"{path}.{ext}", "rb").read()
+            assert text == open(f"{path}.o{ext}", "rb").read(), (path, ext)
+            pkg.binary_to_text(f"{path}.{ext}.bin", width, f"{path}.{ext}.view")
+            assert open(f"{path}.{ext}.view", "rb").read() == text, (path, ext)
+            recs = pkg.read_binary(f"{path}.{ext}.bin", width)
+            lines = text.split(b"\n")
+            assert len(recs) * 2 == len(lines) - 1
+            for k in (0, 1, len(recs) // 2, len(recs) - 1):
+                assert lines[2 * k] == b">" + recs[k][0].encode() + b" "
+                assert recs[k][1].tolist() == [int(x) for x in lines[2 * k + 1].split()]
+    # against the oracle's values directly, record by record
+    bases, off = helpers.concat_reads(reads)
+    ep, ec = ref.query_batch(bases, off, threads=8)
+    for (nm, vals), k in zip(pkg.read_binary(f"{plain}.pml.bin", 2), range(len(reads))):
+        assert nm == names[k] and np.array_equal(vals, ep[off[k]:off[k + 1]])
+    for (nm, vals), k in zip(pkg.read_binary(f"{plain}.cid.bin", 1), range(len(reads))):
+        assert np.array_equal(vals, ec[off[k]:off[k + 1]])
+    tbl.close()
+    # the launcher: `col-bwt query -b` then `col-bwt view`
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idx_file = tmp_path / "tbl.col_pml"
+    idx_file.write_bytes(image.tobytes())
+    launcher = os.path.join(root, "col-bwt_amd", "col-bwt")
+    fa2 = tmp_path / "launch.fa"
+    shutil.copy(plain, fa2)
+    out = subprocess.run([sys.executable, launcher, "query", "-b", "-p", str(fa2), str(tmp_path / "tbl")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert open(f"{fa2}.pml.bin", "rb").read() == open(f"{plain}.pml.bin", "rb").read()
+    out = subprocess.run([sys.executable, launcher, "view", f"{fa2}.cid.bin"], capture_output=True)
+    assert out.returncode == 0 and out.stdout == open(f"{plain}.cid", "rb").read()
