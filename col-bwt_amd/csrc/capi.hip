@@ -75,8 +75,40 @@ struct BatchScratch {
     }
 };
 
+// Page-locked host array for the results of a batch: the device-to-host copy of 3 bytes per
+// base is the largest part of the GPU stage, and runs ~4x faster into pinned memory.  Pinning
+// costs about as much as a copy, so the file entry point keeps its buffers with the handle.
+class PinnedBuf {
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p_) (void)hipHostFree(p_); }
+    bool ensure(size_t bytes) {
+        if (bytes <= cap_) return true;
+        if (p_) (void)hipHostFree(p_);
+        p_ = nullptr;
+        cap_ = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p_, want, 0) != hipSuccess) { p_ = nullptr; (void)hipGetLastError(); return false; }
+        cap_ = want;
+        return true;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p_); }
+
+private:
+    void *p_ = nullptr;
+    size_t cap_ = 0;
+};
+
+constexpr int kFileBatches = 3;   // batches of reads in flight in colbwt_query_file
+
 struct colbwt_index {
     Index ix;
+    // result arrays of colbwt_query_file's batches (one file query at a time uses them)
+    std::mutex file_mu;
+    PinnedBuf file_pml[kFileBatches], file_cid[kFileBatches];
     // Further replicas of the table, one per extra device (colbwt_index_open_devices): each is a
     // handle of its own kind, owned by this one.  The host entry points shard a batch over
     // [this] + more; the device entry points address the replica on the buffers' device.
@@ -428,38 +460,13 @@ int query_batch_all(colbwt_index *idx, const uint8_t *bases, const uint64_t *rea
 
 namespace {
 
-// Page-locked host array for the results of a batch: the device-to-host copy of 3 bytes per
-// base is the largest part of the GPU stage, and runs ~4x faster into pinned memory.
-class PinnedBuf {
-public:
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf &) = delete;
-    PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p_) (void)hipHostFree(p_); }
-    bool ensure(size_t bytes) {
-        if (bytes <= cap_) return true;
-        if (p_) (void)hipHostFree(p_);
-        p_ = nullptr;
-        cap_ = 0;
-        const size_t want = bytes + bytes / 8 + 4096;
-        if (hipHostMalloc(&p_, want, 0) != hipSuccess) { p_ = nullptr; return false; }
-        cap_ = want;
-        return true;
-    }
-    template <typename T>
-    T *as() const { return static_cast<T *>(p_); }
-
-private:
-    void *p_ = nullptr;
-    size_t cap_ = 0;
-};
-
 // One batch of reads on its way through the three stages of colbwt_query_file.
 struct FileBatch {
     std::vector<uint8_t> bases;
     std::vector<uint64_t> off;
     std::vector<std::string> names;
-    PinnedBuf pml, cid;              // u16 or u32 values / u8 col ids, one per base
+    PinnedBuf own_pml, own_cid;      // u16 or u32 values / u8 col ids, one per base
+    PinnedBuf *pml = &own_pml, *cid = &own_cid;   // ... or the handle's, kept across calls
     bool wide = false;
 };
 
@@ -726,8 +733,13 @@ static int query_file_impl(colbwt_index *idx, const char *pattern_path, const st
     if (!(binary ? bp.open(pml_name) : wp.open(pml_name))) return fail(COLBWT_ERR_IO, "cannot create " + pml_name);
     if (!(binary ? bc.open(cid_name) : wc.open(cid_name))) return fail(COLBWT_ERR_IO, "cannot create " + cid_name);
 
-    constexpr int kInFlight = 3;
-    FileBatch pool[kInFlight];
+    FileBatch pool[kFileBatches];
+    std::unique_lock<std::mutex> pinned(idx->file_mu, std::defer_lock);
+    if (pinned.try_lock())               // the handle's pinned arrays, unless another file query holds them
+        for (int k = 0; k < kFileBatches; ++k) {
+            pool[k].pml = &idx->file_pml[k];
+            pool[k].cid = &idx->file_cid[k];
+        }
     BatchQueue free_q, parsed_q, done_q;
     for (auto &b : pool) free_q.push(&b);
     std::atomic<bool> stop{false};   // a later stage failed: the reader stops feeding
@@ -791,15 +803,15 @@ static int query_file_impl(colbwt_index *idx, const char *pattern_path, const st
             // pml_query.cpp:78-85; the two files are laid out side by side, each by several
             // host threads (same bytes, same order as the sequential loop)
             std::thread cid_thread([&] {
-                if (binary) bc.batch<uint8_t>(b->names, b->off.data(), b->cid.as<uint8_t>(), n_reads, host_threads / 2);
-                else wc.batch(b->names, b->off.data(), b->cid.as<uint8_t>(), n_reads, host_threads / 2);
+                if (binary) bc.batch<uint8_t>(b->names, b->off.data(), b->cid->as<uint8_t>(), n_reads, host_threads / 2);
+                else wc.batch(b->names, b->off.data(), b->cid->as<uint8_t>(), n_reads, host_threads / 2);
             });
             if (binary) {
-                if (b->wide) bp.batch<uint16_t>(b->names, b->off.data(), b->pml.as<uint32_t>(), n_reads, host_threads / 2);
-                else bp.batch<uint16_t>(b->names, b->off.data(), b->pml.as<uint16_t>(), n_reads, host_threads / 2);
+                if (b->wide) bp.batch<uint16_t>(b->names, b->off.data(), b->pml->as<uint32_t>(), n_reads, host_threads / 2);
+                else bp.batch<uint16_t>(b->names, b->off.data(), b->pml->as<uint16_t>(), n_reads, host_threads / 2);
             } else {
-                if (b->wide) wp.batch(b->names, b->off.data(), b->pml.as<uint32_t>(), n_reads, host_threads / 2);
-                else wp.batch(b->names, b->off.data(), b->pml.as<uint16_t>(), n_reads, host_threads / 2);
+                if (b->wide) wp.batch(b->names, b->off.data(), b->pml->as<uint32_t>(), n_reads, host_threads / 2);
+                else wp.batch(b->names, b->off.data(), b->pml->as<uint16_t>(), n_reads, host_threads / 2);
             }
             cid_thread.join();
             t_format += now() - t0;
@@ -820,15 +832,15 @@ static int query_file_impl(colbwt_index *idx, const char *pattern_path, const st
         const double t0 = now();
         colbwt_stats st{};
         rc = select_device(idx->ix.device(), g_err);
-        if (rc == COLBWT_OK && (!b->cid.ensure(nb) || !b->pml.ensure(nb * (b->wide ? 4 : 2))))
+        if (rc == COLBWT_OK && (!b->cid->ensure(nb) || !b->pml->ensure(nb * (b->wide ? 4 : 2))))
             rc = fail(COLBWT_ERR_NOMEM, "cannot pin host memory for a batch of results");
         if (rc != COLBWT_OK) {
         } else if (b->wide) {
-            rc = colbwt_query_batch_u32(idx, b->bases.data(), b->off.data(), n_reads, b->pml.as<uint32_t>(),
-                                        b->cid.as<uint8_t>(), &st);
+            rc = colbwt_query_batch_u32(idx, b->bases.data(), b->off.data(), n_reads, b->pml->as<uint32_t>(),
+                                        b->cid->as<uint8_t>(), &st);
         } else {
-            rc = colbwt_query_batch(idx, b->bases.data(), b->off.data(), n_reads, b->pml.as<uint16_t>(),
-                                    b->cid.as<uint8_t>(), &st);
+            rc = colbwt_query_batch(idx, b->bases.data(), b->off.data(), n_reads, b->pml->as<uint16_t>(),
+                                    b->cid->as<uint8_t>(), &st);
         }
         t_gpu += now() - t0;
         if (rc != COLBWT_OK) {

@@ -1,6 +1,7 @@
 // text_writer.cpp -- see text_writer.h (pml_query.cpp:78-85).
 #include "text_writer.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <string.h>
 #include <sys/types.h>
@@ -67,7 +68,8 @@ bool TextWriter::open(const std::string &path) {
 
 bool TextWriter::write_all_(const char *p, size_t n) {
     while (n > 0) {
-        const ssize_t w = ::pwrite(fd_, p, n, (off_t)pos_);
+        ssize_t w = ::pwrite(fd_, p, n, (off_t)pos_);
+        if (w < 0 && errno == ESPIPE) w = ::write(fd_, p, n);   // a pipe or terminal (`col-bwt view`): sequential anyway
         if (w <= 0) return false;
         p += w;
         n -= (size_t)w;

@@ -49,19 +49,23 @@ def main():
                 parts.append(b"\n")
             f.write(b"".join(parts))
     t_write = time.perf_counter() - t0
-    res = []
-    for rep in range(2):
-        t0 = time.perf_counter()
-        st = tbl.query_file(fa)
-        dt = time.perf_counter() - t0
-        res.append(dt)
-    sz = {k: os.path.getsize(fa + k) for k in ("", ".pml", ".cid")}
-    print(json.dumps({"reads": n, "read_len": m, "rows": a.rows, "fasta_bytes": sz[""], "pml_bytes": sz[".pml"],
-                      "cid_bytes": sz[".cid"], "wall_s": res, "Mbase_s": n * m / min(res) / 1e6,
-                      "kernel_ms_last_batch": st.kernel_ms, "h2d_ms": st.h2d_ms, "d2h_ms": st.d2h_ms,
-                      "fasta_gen_s": round(t_write, 1), "cpus": len(os.sched_getaffinity(0))}))
-    for k in ("", ".pml", ".cid"):
-        os.remove(fa + k)
+    for mode, run, exts in (("text", tbl.query_file, (".pml", ".cid")),
+                            ("binary", tbl.query_file_binary, (".pml.bin", ".cid.bin"))):
+        res = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            st = run(fa)
+            dt = time.perf_counter() - t0
+            res.append(dt)
+        sz = {k: os.path.getsize(fa + k) for k in ("",) + exts}
+        print(json.dumps({"mode": mode, "reads": n, "read_len": m, "rows": a.rows, "fasta_bytes": sz[""],
+                          "pml_bytes": sz[exts[0]], "cid_bytes": sz[exts[1]], "wall_s": [round(x, 4) for x in res],
+                          "Mbase_s": n * m / min(res) / 1e6, "kernel_ms": st.kernel_ms, "h2d_ms": st.h2d_ms, "d2h_ms": st.d2h_ms,
+                          "fasta_gen_s": round(t_write, 1), "cpus": len(os.sched_getaffinity(0)),
+                          "tmpdir": tmp}), flush=True)
+        for k in exts:
+            os.remove(fa + k)
+    os.remove(fa)
     os.rmdir(tmp)
 
 
