@@ -27,6 +27,7 @@ EXPORTS = (
     "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_query_file_binary",
     "colbwt_binary_to_text", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
+    "colbwt_col_split", "colbwt_col_split_arrays", "colbwt_col_split_error",
 )
 
 
@@ -284,6 +285,39 @@ def build_col_pml_arrays(heads, lens, col_ids, split_pos, thr_pos):
     out = np.zeros(need.value, np.uint8)
     _check_build(lib().colbwt_build_col_pml_arrays(*args, out.ctypes.data, out.size, C.byref(need)))
     return out
+
+
+def col_split(prefix, mode="tunnels", split_rate=1, device=0):
+    """`col_split <prefix> -m mode -s rate` (src/col_split.cpp:62-140, with build_FL folded in): writes
+    <prefix>.col_runs and <prefix>.col_ids."""
+    L = lib()
+    L.colbwt_col_split_error.restype = C.c_char_p
+    rc = L.colbwt_col_split(os.fsencode(prefix), 1 if mode == "all" else 0, int(split_rate), int(device))
+    if rc != 0:
+        raise ColbwtError(rc, L.colbwt_col_split_error().decode())
+
+
+def col_split_arrays(heads, lens, mum_len, mum_pos, num_docs, mode="tunnels", split_rate=1, device=0):
+    """-> (split positions uint64 ascending, col ids uint8, n): what .col_runs / .col_ids would hold."""
+    L = lib()
+    L.colbwt_col_split_error.restype = C.c_char_p
+    L.colbwt_col_split_arrays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                          C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                          C.POINTER(C.c_uint64)]
+    heads = np.ascontiguousarray(heads, np.uint8)
+    lens = np.ascontiguousarray(lens, np.uint64)
+    mum_len = np.ascontiguousarray(mum_len, np.uint64)
+    mum_pos = np.ascontiguousarray(mum_pos, np.uint64)
+    cap = int(lens.sum()) + 8
+    pos = np.zeros(cap, np.uint64)
+    ids = np.zeros(cap, np.uint8)
+    k, n = C.c_uint64(0), C.c_uint64(0)
+    rc = L.colbwt_col_split_arrays(heads.ctypes.data, heads.size, lens.ctypes.data, mum_len.ctypes.data, mum_pos.ctypes.data,
+                                   mum_len.size, int(num_docs), 1 if mode == "all" else 0, int(split_rate), int(device),
+                                   pos.ctypes.data, cap, C.byref(k), ids.ctypes.data, C.byref(n))
+    if rc != 0:
+        raise ColbwtError(rc, L.colbwt_col_split_error().decode())
+    return pos[:k.value].copy(), ids[:k.value].copy(), int(n.value)
 
 
 def _check_build(rc):

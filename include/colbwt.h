@@ -197,6 +197,32 @@ int colbwt_build_col_pml_arrays(const uint8_t *heads, uint64_t n_heads, const ui
                                 uint64_t n_splits, const uint64_t *thr_pos, uint64_t n_thr, void *out,
                                 uint64_t out_cap, uint64_t *out_len);
 
+/* ---- sub-run splitting (SURVEY.md 8(f) "next" #2) -------------------------- */
+
+/* build_FL + col_split (src/build_FL.cpp:27-74, src/col_split.cpp:62-140; include/ds/FL_table.hpp,
+ * include/col_split.hpp): multi-MUMs -> where sub-runs start and their chain statistic.
+ * `col_split <prefix> -m tunnels|all -s <rate>`: reads <prefix>.bwt.heads, .bwt.len and .col_mums
+ * (5-byte num_docs, then 5-byte (length, position) pairs; position = rank in F / suffix-array
+ * order of the first of num_docs consecutive suffixes, ascending), writes <prefix>.col_runs (a plain
+ * sdsl::bit_vector: u64 length in bits + words) and <prefix>.col_ids (one byte per set bit) --
+ * the inputs of colbwt_build_col_pml.  The FL table is rebuilt from the RLBWT instead of read from
+ * the reference's .FL_table file (which embeds an sdsl sd_vector).  Every multi-MUM is FL-stepped on
+ * the device (the reference steps them one after the other, twice); the overlap sweep
+ * (find_col_runs, col_split.hpp:258-342) runs on the host.  The reference's -o overlap option is
+ * parsed there but never used (col_split.hpp:215), so it has no counterpart.  `all` mode: up to
+ * 1024 documents.  Needs 4 (tunnels) or 8 (all) bytes of HBM per BWT position. */
+#define COLBWT_SPLIT_TUNNELS 0
+#define COLBWT_SPLIT_ALL 1
+int colbwt_col_split(const char *prefix, int mode, int split_rate, int device);
+/* Same over decoded arrays; results as colbwt_build_col_pml_arrays takes them: split_pos = the
+ * ascending positions of the set bits of .col_runs (room for `cap`), col_ids one byte each,
+ * *n_split their number (also when the arrays are too small, then ERR_ARG), *bwt_len = n. */
+int colbwt_col_split_arrays(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens, const uint64_t *mum_len,
+                            const uint64_t *mum_pos, uint64_t n_mums, uint32_t num_docs, int mode, int split_rate,
+                            int device, uint64_t *split_pos, uint64_t cap, uint64_t *n_split, uint8_t *col_ids,
+                            uint64_t *bwt_len);
+const char *colbwt_col_split_error(void);
+
 /* ---- multi-GPU gather codec (the path's one exchange step) -----------------
  * The reference has no counterpart: its reads are processed by one process
  * (pml_query.cpp:74).  With the reads sharded over N GPUs the per-base results

@@ -16,9 +16,9 @@ _LIB_PATH = os.path.join(_HERE, "libcolbwt_oracle.so")
 
 def build(force=False):
     """Compile the C restatement (gcc); idempotent."""
-    src = os.path.join(_HERE, "colbwt_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("colbwt_oracle.c", "colsplit_oracle.c", "colbwt_oracle.h", "colsplit_oracle.h")]
     if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-C", _HERE, "libcolbwt_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -134,3 +134,38 @@ def build_col_pml(heads, lens, col_ids, split_pos, thr_pos):
                                split_pos.ctypes.data, split_pos.size, thr_pos.ctypes.data, thr_pos.size,
                                out.ctypes.data, cap)
     return out[:n].copy()
+
+
+class _FL(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("r", C.c_uint64), ("ch", C.c_void_p), ("idx", C.c_void_p),
+                ("interval", C.c_void_p), ("offset", C.c_void_p), ("L_head", C.c_void_p)]
+
+
+def col_split(heads, lens, mum_len, mum_pos, num_docs, mode, split_rate=1):
+    """build_FL + col_split (src/build_FL.cpp, src/col_split.cpp; colsplit_oracle.c): returns
+    (split_positions uint64 ascending, col_ids uint8 as .col_ids would hold them, n, stats) with
+    stats = (col id runs, total runs, col chars) as the reference prints them."""
+    L = lib()
+    L.oracle_fl_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(_FL)]
+    L.oracle_fl_free.argtypes = [C.POINTER(_FL)]
+    L.oracle_col_split.argtypes = [C.POINTER(_FL), C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    heads = np.ascontiguousarray(heads, np.uint8)
+    lens = np.ascontiguousarray(lens, np.uint64)
+    mum_len = np.ascontiguousarray(mum_len, np.uint64)
+    mum_pos = np.ascontiguousarray(mum_pos, np.uint64)
+    t = _FL()
+    if L.oracle_fl_build(heads.ctypes.data, heads.size, lens.ctypes.data, C.byref(t)) != 0:
+        raise ValueError("oracle_fl_build failed")
+    n = int(t.n)
+    bits = np.zeros((n + 63) // 64 + 1, np.uint64)
+    cap = n + 8
+    ids = np.zeros(cap, np.uint8)
+    n_ids = C.c_uint64(0)
+    stats = np.zeros(3, np.uint64)
+    L.oracle_col_split(C.byref(t), mum_len.ctypes.data, mum_pos.ctypes.data, mum_len.size, int(num_docs),
+                       1 if mode == "all" else 0, int(split_rate), bits.ctypes.data, ids.ctypes.data, cap,
+                       C.byref(n_ids), stats.ctypes.data)
+    L.oracle_fl_free(C.byref(t))
+    pos = np.flatnonzero(np.unpackbits(bits.view(np.uint8), bitorder="little")[:n]).astype(np.uint64)
+    return pos, ids[:n_ids.value].copy(), n, tuple(int(x) for x in stats)

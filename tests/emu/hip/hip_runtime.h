@@ -112,6 +112,12 @@ static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) {
 static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); unsigned long long o = *p; *p = o + v; return o;
 }
+static inline uint32_t atomicMax(uint32_t *p, uint32_t v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; if (v > o) *p = v; return o;
+}
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); unsigned long long o = *p; if (v > o) *p = v; return o;
+}
 static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
     std::lock_guard<std::mutex> g(emu::atomic_mu); uint32_t o = *p; if (v < o) *p = v; return o;
 }
