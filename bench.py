@@ -30,6 +30,7 @@ from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 GATHER_CEILING_G = 39.5        # G random 32-byte rows (2 x 16 B loads, one line fill)/s this chip sustains on a 16 GiB table
+GATHER_CEILING_LINE_G = 47.0   # G random whole 128-byte lines/s, fetched lane-cooperatively into LDS, on a 128 GiB table
 ALG_BYTES_PER_BASE = 27
 
 
@@ -188,22 +189,40 @@ def main():
         value = world * n_bases * args.steps / elapsed
         achieved = ALG_BYTES_PER_BASE * bases_per_launch / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
+        traffic_source = None
         line_fills = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         is_baseline_cfg = (args.rows, args.reads, args.read_len) == (200_000_000, 10_000_000, 150)
+        kernel_name = (f"fat_query_kernel<{info.layout_shape >> 8},u16>" if info.layout == 4
+                       else f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>")
         if is_baseline_cfg and n_chunks == 1 and os.path.exists(tpath):
+            # PMC counters cannot be read inside this run: `traffic` is what the committed rocprofv3
+            # passes measured for THIS kernel -- reported only while the kernel sources still hash to
+            # what they were when the profile was taken, null otherwise (tools/profile_round.sh +
+            # tools/summarize_profile.py <tag> --set-traffic refresh it).
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from summarize_profile import kernel_sources_sha
             tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch")
-            if info.layout == 3 and tj.get("read_requests_per_launch"):
+            same_kernel = kernel_name.split("<")[0] in (tj.get("kernel") or "") and \
+                kernel_name.split("<")[1].split(",")[0] in (tj.get("kernel") or "")
+            fresh = tj.get("kernel_sources_sha") == kernel_sources_sha(ROOT)
+            traffic_source = {"profile": f"profiles/{tj.get('tag')}_summary.json", "taken_at_commit": tj.get("taken_at_commit"),
+                              "kernel": tj.get("kernel"), "kernel_sources_unchanged": fresh, "same_kernel": same_kernel}
+            if fresh and same_kernel:
+                traffic = tj.get("hbm_bytes_per_launch")
+            if fresh and same_kernel and tj.get("read_requests_per_launch"):
                 # What actually bounds the kernel: the chip's rate of random
                 # 128-byte line fills, measured by tools/gather_littles.sh for this access shape.
                 rd, wr = tj["read_requests_per_launch"], tj["write_requests_per_launch"]
                 sec = avg_launch_ms * 1e-3
+                ceiling = GATHER_CEILING_LINE_G if info.layout == 4 else GATHER_CEILING_G
                 line_fills = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
                               "achieved_G_per_s": rd / sec / 1e9, "write_G_per_s": wr / sec / 1e9,
-                              "ceiling_G_per_s": GATHER_CEILING_G, "frac": rd / sec / 1e9 / GATHER_CEILING_G,
-                              "ceiling_source": "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B "
-                                                "loads per line, reads only)"}
+                              "ceiling_G_per_s": ceiling, "frac": rd / sec / 1e9 / ceiling,
+                              "ceiling_source": ("profiles/r02_gather_line_rows.jsonl (dependent random whole lines, "
+                                                 "lane-cooperative LDS-DMA, reads only)" if info.layout == 4 else
+                                                 "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B "
+                                                 "loads per line, reads only)")}
         out = {
             "metric": "query bases/s", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -224,9 +243,8 @@ def main():
                                       4: f"line rows K={info.layout_shape >> 8} KS={info.layout_shape & 255}"}.get(info.layout, "?"),
                        "hbm_table_rows": int(info.table_rows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": (f"fat_query_kernel<{info.layout_shape >> 8},{info.layout_shape & 255},u16>" if info.layout == 4
-                                    else f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name,
                          "avg_launch_ms": avg_launch_ms,
                          "launches": launches, "alg_bytes_per_base": ALG_BYTES_PER_BASE,
                          "bases_per_launch": bases_per_launch, "line_fills": line_fills},
@@ -277,14 +295,18 @@ def main():
         if lf and os.path.exists(gb):
             try:
                 import subprocess
-                res = subprocess.run([gb, "16384", "524288", "1500", "10", "2", "0"], capture_output=True, text=True,
-                                     timeout=120)
+                tbl.close()                      # the calibration table needs the HBM the index holds
+                torch.cuda.empty_cache()
+                gb_args = ["65536", "196608", "1500", "16", "2", "0"] if info.layout == 4 else ["16384", "524288", "1500", "10", "2", "0"]
+                res = subprocess.run([gb] + gb_args, capture_output=True, text=True, timeout=120)
                 rates = [json.loads(line)["Gsteps_per_s"] for line in res.stdout.splitlines() if line.startswith("{")]
                 if rates:
                     lf["ceiling_G_per_s"] = max(rates)
                     lf["frac"] = lf["achieved_G_per_s"] / lf["ceiling_G_per_s"]
-                    lf["ceiling_source"] = "tools/gather_bench on this box, after the timed region " \
-                                           "(dependent random loads of one aligned 32-byte row = 2 x 16 B, 16 GiB table, reads only)"
+                    lf["ceiling_source"] = "tools/gather_bench on this box, after the timed region " + (
+                        "(dependent random whole 128-byte lines, lane-cooperative LDS-DMA, 64 GiB table, reads only)"
+                        if info.layout == 4 else
+                        "(dependent random loads of one aligned 32-byte row = 2 x 16 B, 16 GiB table, reads only)")
             except Exception as e:      # the calibration is optional: keep the recorded constant
                 lf["ceiling_note"] = f"live calibration failed: {e}"
     if rank == 0:

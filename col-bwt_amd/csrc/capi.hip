@@ -342,7 +342,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     if (d_order) HOST_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HOST_HIP(hipEventRecord(S.ev[1], stream));
     if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
-        launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+        launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, n_bases, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else
@@ -691,7 +691,7 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
         API_HIP(hipEventRecord(e0, stream));
     }
     if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
-        launch_fat_query(idx->ix.table_fat(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+        launch_fat_query(idx->ix.table_fat(), d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     else

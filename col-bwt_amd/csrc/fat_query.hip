@@ -170,11 +170,11 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
                       PmlT *__restrict__ pml, uint8_t *__restrict__ cid) {
     constexpr bool kWide = sizeof(PmlT) == 4;
     __shared__ uint4 s_stage[kWaves][8][64];       // per wave: instruction q's 64 x 16 bytes
-    __shared__ uint4 s_win[kWaves][2][64];         // read bytes (lane_io.h DmaRing)
-    // 40 KB in all: four workgroups (16 waves) fit a CU's 160 KB.  The rows the lanes want are
-    // handed to their groups through the last 256 bytes of the wave's own stage area, which the
-    // trip's last DMA (q = 7) fills only after every lane has read them; the chunk counter of the
-    // workgroup lives in global memory for want of 4 more bytes.
+    __shared__ uint4 s_win[kWaves][4][64];         // read bytes (lane_io.h LaneWindow)
+    // 48 KB in all: three workgroups (12 waves) per CU -- the registers of the collector allow no
+    // more.  The rows the lanes want are handed to their groups through the last 256 bytes of the
+    // wave's own stage area, which the trip's last DMA (q = 7) fills only after every lane has
+    // read them; the chunk counter of the workgroup lives in global memory.
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, g8 = lane & ~7u, p = lane & 7u;
     uint32_t *const s_jx = reinterpret_cast<uint32_t *>(&s_stage[wave][7][48]);   // 64 dwords
     ChunkPlan plan;
@@ -188,7 +188,7 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
     done = !rc.enter_chunk(plan, claim);
 
     OutAccRun acc;
-    DmaRing win;
+    LaneWindow win;
     win.init(rc.off + rc.k - 1);
     uint4 (*const my_win)[64] = s_win[wave];
 
@@ -258,13 +258,12 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
             }
         }
         FAT_CLOCK(6);
-        if (live) win.request(bases, g);
+        if (live && win.avail(g) < (k < 8u ? (uint32_t)k : 8u)) win.request(my_win, bases, g);
         if (step_back) { rc.in_next = read_off[rc.r - 1]; rc.next_in_flight = true; }
         if (!done && rc.fetch_pending) rc.request_chunk(plan, read_off);
         FAT_CLOCK(1);
         lds_dma_landed();
         rc.commit();
-        win.land(my_win, lane);
         FAT_CLOCK(2);
 
         const uint32_t have = live ? win.avail(g) : 0u;      // read bytes at hand (a fresh chunk starts with 1 .. 16)
@@ -422,14 +421,18 @@ uint32_t resident_blocks() {
 }
 
 template <int K, typename PmlT>
-void launch_typed(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, PmlT *d_pml,
-                  uint8_t *d_cid, hipStream_t stream) {
+void launch_typed(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
+                  PmlT *d_pml, uint8_t *d_cid, hipStream_t stream) {
     const uint64_t want_blocks = (n_reads + kQueryBlock - 1) / kQueryBlock;
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want_blocks, resident_blocks<K, PmlT>()), kFatClaimBlocks);
     // Reads per bulk chunk: a chunk ends with a ragged flush of the collector, so it should hold a
-    // few reads; the last tenth of a workgroup's share (at least two reads per lane) goes out read
-    // by read.
-    uint32_t big = 8;
+    // few reads -- but no more than a sixth of a lane's share of the BASES, or a few lanes end up
+    // with most of a workgroup's work (1 M reads of 10 kbp are five reads per lane: chunks of eight
+    // took 1.6 times as long as single reads).  The last tenth of a workgroup's share (at least two
+    // reads per lane) goes out read by read.
+    const uint64_t lanes = (uint64_t)blocks * kQueryBlock;
+    const uint64_t avg_len = std::max<uint64_t>(n_bases / std::max<uint64_t>(n_reads, 1), 1);
+    uint32_t big = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_bases / lanes / 6 / avg_len, 1), 8);
     uint32_t tail_permille = 100;
     if (const char *e = getenv("COLBWT_LINE_ROWS_CHUNK")) {   // experiments: "<big>[,<tail permille>]"
         const int v = atoi(e);
@@ -446,21 +449,21 @@ void launch_typed(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_r
 }
 
 template <int K>
-void launch_steps(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, void *d_pml,
-                  int pml_bytes, uint8_t *d_cid, hipStream_t stream) {
-    if (pml_bytes == 2) launch_typed<K, uint16_t>(T, d_bases, d_read_off, n_reads, (uint16_t *)d_pml, d_cid, stream);
-    else launch_typed<K, uint32_t>(T, d_bases, d_read_off, n_reads, (uint32_t *)d_pml, d_cid, stream);
+void launch_steps(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
+                  void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream) {
+    if (pml_bytes == 2) launch_typed<K, uint16_t>(T, d_bases, d_read_off, n_reads, n_bases, (uint16_t *)d_pml, d_cid, stream);
+    else launch_typed<K, uint32_t>(T, d_bases, d_read_off, n_reads, n_bases, (uint32_t *)d_pml, d_cid, stream);
 }
 
 }  // namespace
 
 // d_order (the length-sorted lane assignment of the other layouts) is not used: persistent lanes
 // claiming chunks of consecutive reads balance ragged batches by themselves.
-void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, void *d_pml,
-                      int pml_bytes, uint8_t *d_cid, const uint32_t *, hipStream_t stream) {
+void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
+                      void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *, hipStream_t stream) {
     if (n_reads == 0) return;
 #define X(K) \
-    if (T.steps == K) launch_steps<K>(T, d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, stream);
+    if (T.steps == K) launch_steps<K>(T, d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, stream);
     COLBWT_FAT_STEPS(X)
 #undef X
 }

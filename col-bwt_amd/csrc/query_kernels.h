@@ -81,7 +81,7 @@ bool fat_steps_supported(int steps);
 int build_fat(const DevTable &T, const HintChars &chars, int steps, FatTable &out, FatBuffers &buf, std::string &err,
               const std::function<void()> &source_done);
 // The query over line rows (fat_query.hip).
-void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                       void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
 void launch_fat_synth_reads(const FatTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                             uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-permille", type=int, default=10)
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--pml-bytes", type=int, default=2, help="2 = u16 PML (reads <= 65535 bases), 4 = u32")
     ap.add_argument("--thr-mode", type=int, default=0, help="0: thresholds uniform in [0,n) (C2 recipe); 1: between runs")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
@@ -73,10 +74,10 @@ def main():
     sums = {}
     for rep in range(a.reps + 1):
         for name, L, h, times in variants:
-            d_pml = torch.zeros(nb + 16, dtype=torch.int16, device=dev)
+            d_pml = torch.zeros(nb + 16, dtype=torch.int16 if a.pml_bytes == 2 else torch.int32, device=dev)
             d_cid = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
             st = Stats()
-            rc = L.colbwt_query_device(h, d_bases.data_ptr(), d_off.data_ptr(), n_reads, nb, d_pml.data_ptr(), 2,
+            rc = L.colbwt_query_device(h, d_bases.data_ptr(), d_off.data_ptr(), n_reads, nb, d_pml.data_ptr(), a.pml_bytes,
                                        d_cid.data_ptr(), None, C.byref(st))
             assert rc == 0, L.colbwt_last_error()
             if rep:
@@ -88,7 +89,7 @@ def main():
     for name, L, h, times in variants:
         print(json.dumps({"lib": name, "ms": round(float(np.mean(times)), 3), "min_ms": round(min(times), 3),
                           "Gbase_s": round(nb / np.mean(times) / 1e6, 3), "checksum_ok": sums[name] == ref,
-                          "rows": a.rows, "reads": n_reads, "read_len": m}), flush=True)
+                          "rows": a.rows, "reads": n_reads, "read_len": m, "pml_bytes": a.pml_bytes}), flush=True)
 
 
 if __name__ == "__main__":

@@ -23,8 +23,25 @@ import shutil
 import sys
 
 
+KERNEL_SOURCES = ("fat_query.hip", "fat_layout.h", "fat_build.hip", "lane_io.h", "sk_query.hip", "sk_layout.h", "query_kernels.hip",
+                  "lf_device.h", "device_layout.h")
+
+
+def kernel_sources_sha(root):
+    """sha256 over the sources that decide the query kernels' memory traffic: bench.py reports the
+    recorded traffic only while this still matches (no git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(root, "col-bwt_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     tag = sys.argv[1]
+    if tag.startswith("-"):
+        sys.exit(f"summarize_profile.py: '{tag}' is not a profile tag")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(root, "profiles")
@@ -64,7 +81,14 @@ def main():
     q = sorted([d for k, d in summary["kernels"].items() if "query_kernel" in k],
                key=lambda d: -d.get("total_ns", 0))
     if q and "hbm_bytes_per_launch" in q[0] and len(sys.argv) > 2 and sys.argv[2] == "--set-traffic":
-        json.dump({"tag": tag, "hbm_bytes_per_launch": q[0]["hbm_bytes_per_launch"],
+        import subprocess
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
+        kname = [k for k, d in summary["kernels"].items() if d is q[0]][0]
+        json.dump({"tag": tag, "kernel": kname, "taken_at_commit": commit, "kernel_sources_sha": kernel_sources_sha(root),
+                   "hbm_bytes_per_launch": q[0]["hbm_bytes_per_launch"],
                    "hbm_read_bytes_per_launch": q[0]["hbm_read_bytes_per_launch"],
                    "hbm_write_bytes_per_launch": q[0]["hbm_write_bytes_per_launch"],
                    "read_requests_per_launch": q[0]["pmc_per_launch"].get("TCC_EA0_RDREQ_sum"),
