@@ -28,6 +28,7 @@ EXPORTS = (
     "colbwt_binary_to_text", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
     "colbwt_col_split", "colbwt_col_split_arrays", "colbwt_col_split_error",
+    "colbwt_rlbwt_build_text", "colbwt_rlbwt_build_files", "colbwt_rlbwt_get", "colbwt_rlbwt_free", "colbwt_rlbwt_error",
 )
 
 
@@ -318,6 +319,58 @@ def col_split_arrays(heads, lens, mum_len, mum_pos, num_docs, mode="tunnels", sp
     if rc != 0:
         raise ColbwtError(rc, L.colbwt_col_split_error().decode())
     return pos[:k.value].copy(), ids[:k.value].copy(), int(n.value)
+
+
+class _RlbwtView(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("n_runs", C.c_uint64), ("n_mums", C.c_uint64), ("n_docs", C.c_uint32), ("rounds", C.c_int32),
+                ("heads", C.POINTER(C.c_uint8)), ("lens", C.POINTER(C.c_uint64)), ("thr_pos", C.POINTER(C.c_uint64)),
+                ("mum_len", C.POINTER(C.c_uint64)), ("mum_pos", C.POINTER(C.c_uint64))]
+
+
+def _rlbwt_result(L, handle):
+    v = _RlbwtView()
+    L.colbwt_rlbwt_get.argtypes = [C.c_void_p, C.POINTER(_RlbwtView)]
+    L.colbwt_rlbwt_free.argtypes = [C.c_void_p]
+    L.colbwt_rlbwt_get(handle, C.byref(v))
+
+    def arr(ptr, count, dtype):
+        return np.ctypeslib.as_array(ptr, shape=(count,)).astype(dtype, copy=True) if count else np.zeros(0, dtype)
+    out = dict(n=int(v.n), n_docs=int(v.n_docs), rounds=int(v.rounds), heads=arr(v.heads, v.n_runs, np.uint8),
+               lens=arr(v.lens, v.n_runs, np.uint64), thr=arr(v.thr_pos, v.n_runs, np.uint64),
+               mum_len=arr(v.mum_len, v.n_mums, np.uint64), mum_pos=arr(v.mum_pos, v.n_mums, np.uint64))
+    L.colbwt_rlbwt_free(handle)
+    return out
+
+
+def rlbwt_from_text(text, doc_start, min_mum=20, device=0):
+    """RLBWT, thresholds and multi-MUMs of a prepared text (separators 1, final 0) on the device:
+    -> dict(n, n_docs, rounds, heads, lens, thr, mum_len, mum_pos)."""
+    L = lib()
+    L.colbwt_rlbwt_error.restype = C.c_char_p
+    L.colbwt_rlbwt_build_text.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]
+    t = np.frombuffer(bytes(text), np.uint8)
+    ds = np.ascontiguousarray(doc_start, np.uint64)
+    h = C.c_void_p()
+    rc = L.colbwt_rlbwt_build_text(t.ctypes.data, t.size, ds.ctypes.data, ds.size, int(min_mum), int(device), C.byref(h))
+    if rc != 0:
+        raise ColbwtError(rc, L.colbwt_rlbwt_error().decode())
+    return _rlbwt_result(L, h)
+
+
+def rlbwt_from_fastas(paths, out_prefix=None, min_mum=20, revcomp=False, device=0):
+    """`mumemto mum -K -R -T` of the reference's driver (col-bwt.py:121-145): one document per file;
+    writes <out_prefix>.bwt.heads / .bwt.len / .thr_pos / .col_mums when given; returns the arrays."""
+    L = lib()
+    L.colbwt_rlbwt_error.restype = C.c_char_p
+    L.colbwt_rlbwt_build_files.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.c_char_p,
+                                           C.POINTER(C.c_void_p)]
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    h = C.c_void_p()
+    rc = L.colbwt_rlbwt_build_files(arr, len(paths), int(bool(revcomp)), int(min_mum), int(device),
+                                    os.fsencode(out_prefix) if out_prefix else None, C.byref(h))
+    if rc != 0:
+        raise ColbwtError(rc, L.colbwt_rlbwt_error().decode())
+    return _rlbwt_result(L, h)
 
 
 def _check_build(rc):

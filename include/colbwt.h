@@ -223,6 +223,50 @@ int colbwt_col_split_arrays(const uint8_t *heads, uint64_t n_heads, const uint64
                             uint64_t *bwt_len);
 const char *colbwt_col_split_error(void);
 
+/* ---- RLBWT, thresholds and multi-MUMs from FASTA (SURVEY.md 8(f) "next" #4) ---- */
+
+/* What the reference's driver takes from `mumemto mum -K -R -T -l <min> [-r]` (scripts/col-bwt.py:
+ * 121-145): <prefix>.bwt.heads (one character per BWT run), .bwt.len (5-byte run lengths),
+ * .thr_pos (5-byte threshold position per run, col_bwt.hpp:446-448) and .col_mums (5-byte num_docs,
+ * then 5-byte (length, position) pairs, col_split.cpp:90-106) -- the inputs of colbwt_col_split and
+ * colbwt_build_col_pml.  mumemto itself is an un-vendored dependency, so its conventions are
+ * restated here and UNVERIFIED against it ("parity unpinned"):
+ *   text        every record of every file as it is + separator 1 (+ its reverse complement + 1 when
+ *               `revcomp`; one document per file), then one final 0; suffixes compare byte-wise
+ *   threshold   first position of the minimum LCP in (end of the previous run of the character,
+ *               head of this run]; 0 for a character's first run
+ *   multi-MUM   num_docs consecutive suffixes, one from every document, that share >= min_mum
+ *               characters (never across a separator), more than with either neighbouring suffix,
+ *               and are not all preceded by the same character; position = suffix-array rank of
+ *               the first, length = the shared prefix
+ * The suffix array (prefix doubling over rocPRIM radix sorts), the LCP array, the runs, the
+ * thresholds and the multi-MUM scan all run on the device.  Text < 2^32-1 characters, <= 4096
+ * documents; HBM 29 bytes per character + 4 per doubling round. */
+typedef struct colbwt_rlbwt colbwt_rlbwt;
+typedef struct colbwt_rlbwt_view {
+    uint64_t n;        /* BWT length */
+    uint64_t n_runs;
+    uint64_t n_mums;
+    uint32_t n_docs;
+    int32_t rounds;    /* prefix-doubling rounds the suffix sort took */
+    const uint8_t *heads;      /* n_runs */
+    const uint64_t *lens;      /* n_runs */
+    const uint64_t *thr_pos;   /* n_runs */
+    const uint64_t *mum_len;   /* n_mums */
+    const uint64_t *mum_pos;   /* n_mums, ascending */
+} colbwt_rlbwt_view;
+/* text[0..n): separators 1 in place, text[n-1] its only 0; doc_start[d] = first character of
+ * document d, ascending from 0. */
+int colbwt_rlbwt_build_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, uint32_t n_docs,
+                            uint64_t min_mum, int device, colbwt_rlbwt **out);
+/* FASTA/FASTQ(.gz) files, one document each; writes the four files when out_prefix is not NULL,
+ * hands the result back when `out` is not NULL. */
+int colbwt_rlbwt_build_files(const char *const *fastas, uint32_t n_files, int revcomp, uint64_t min_mum, int device,
+                             const char *out_prefix, colbwt_rlbwt **out);
+void colbwt_rlbwt_get(const colbwt_rlbwt *h, colbwt_rlbwt_view *view);   /* pointers live until _free */
+void colbwt_rlbwt_free(colbwt_rlbwt *h);
+const char *colbwt_rlbwt_error(void);
+
 /* ---- multi-GPU gather codec (the path's one exchange step) -----------------
  * The reference has no counterpart: its reads are processed by one process
  * (pml_query.cpp:74).  With the reads sharded over N GPUs the per-base results

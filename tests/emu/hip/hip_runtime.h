@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -47,6 +48,7 @@ struct Barrier {
     std::condition_variable cv;
     uint32_t expected = 0, arrived = 0, generation = 0;
     uint64_t ballot_acc = 0, ballot_out = 0;
+    uint64_t xchg[64] = {};   // __shfl_* hand-over of the wave
     void reset(uint32_t n) { expected = n; arrived = 0; generation = 0; ballot_acc = 0; }
     // returns the OR of `bits` over all participants of this generation
     uint64_t arrive(uint64_t bits) {
@@ -87,6 +89,23 @@ static inline unsigned long long __ballot(int pred) {
     return emu::ctx.wave->arrive(pred ? (1ull << (emu::ctx.tid.x & 63)) : 0ull);
 }
 static inline int __any(int pred) { return __ballot(pred) != 0; }
+// Wave shuffles (all 64 lanes take part): values pass through the wave's exchange slots.
+template <typename T>
+static inline T emu_shfl(T v, int src_lane) {
+    emu::Barrier *w = emu::ctx.wave;
+    w->xchg[emu::ctx.tid.x & 63] = (uint64_t)v;
+    w->arrive(0);
+    const T r = (T)w->xchg[src_lane & 63];
+    w->arrive(0);
+    return r;
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask) { return emu_shfl(v, (int)(emu::ctx.tid.x & 63) ^ mask); }
+template <typename T>
+static inline T __shfl_down(T v, int delta) {
+    const int lane = (int)(emu::ctx.tid.x & 63);
+    return emu_shfl(v, lane + delta < 64 ? lane + delta : lane);
+}
 // Cross-lane hand-over through LDS inside one wave: the 64 emulated lanes are OS threads, so the
 // compiler-only barrier of the GPU build is a real one here.
 #define __builtin_amdgcn_wave_barrier() ((void)emu::ctx.wave->arrive(0))
@@ -126,6 +145,9 @@ static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
     emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
 
 static inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+using std::max;
+using std::min;
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }

@@ -1,0 +1,227 @@
+"""Front of the pipeline (SURVEY.md 8(f) "next" #4): FASTA documents -> RLBWT, thresholds, multi-MUMs.
+
+PARITY UNPINNED (mumemto, which writes these files for the reference, is neither in the reference
+tree nor in this image): the tests pin the product to oracle/rlbwt_oracle.py -- the published
+meaning of the files written independently -- and the oracle's multi-MUMs to a brute-force
+enumeration of substrings that uses no suffix array.
+
+CPU tier: oracle self-checks; the product's HIP sources under the SIMT emulator == oracle.
+GPU tier (-m gpu): the device construction == oracle on related sequences (with and without reverse
+complements); the whole chain FASTA -> build_rlbwt -> col_split -> build_col_bwt -> query equals the
+oracle chain, file by file.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import rlbwt_oracle as ro  # noqa: E402
+
+ACGT = np.frombuffer(b"ACGT", np.uint8)
+
+
+def related_docs(rng, n_docs, length, rate, records=1, with_n=False):
+    """n_docs documents of `records` records each: copies of one random sequence with substitutions,
+    a few insertions/deletions, optionally a stretch of N."""
+    base = rng.choice(ACGT, size=length)
+    docs = []
+    for _ in range(n_docs):
+        s = base.copy()
+        mut = rng.random(length) < rate
+        s[mut] = rng.choice(ACGT, size=int(mut.sum()))
+        s = s.tolist()
+        for _ in range(int(rng.integers(0, 3))):
+            at = int(rng.integers(0, len(s)))
+            if rng.random() < 0.5:
+                del s[at:at + int(rng.integers(1, 5))]
+            else:
+                s[at:at] = rng.choice(ACGT, size=int(rng.integers(1, 5))).tolist()
+        if with_n:
+            at = int(rng.integers(0, max(1, len(s) - 10)))
+            s[at:at + 6] = [ord("N")] * 6
+        s = bytes(s)
+        cuts = sorted(rng.choice(np.arange(1, len(s)), size=records - 1, replace=False).tolist()) if records > 1 else []
+        docs.append([s[a:b] for a, b in zip([0] + cuts, cuts + [len(s)])])
+    return docs
+
+
+def test_oracle_on_the_survey_text():
+    """GATTACAGATTACCGATAACA: the multi-MUM of the two halves' GATTAC is
+    at suffix-array rank 15 in the survey's single-terminator text; here the same text as two
+    documents."""
+    res = ro.build([[b"GATTACA"], [b"GATTACCGATAACA"]], min_len=3)
+    text = res["text"]
+    assert text == b"GATTACA\x01GATTACCGATAACA\x01\x00"
+    assert sorted(res["sa"]) == list(range(len(text))) and all(text[a:] < text[b:] for a, b in zip(res["sa"], res["sa"][1:]))
+    assert sum(res["lens"]) == len(text) and all(a != b for a, b in zip(res["heads"], res["heads"][1:]))
+    assert res["mums"] == ro.brute_force_mums(text, res["doc_start"], 3)
+    (length, rank), = [m for m in res["mums"] if m[0] == 6]
+    assert text[res["sa"][rank]:][:6] == b"GATTAC" and text[res["sa"][rank + 1]:][:6] == b"GATTAC"
+
+
+def test_oracle_mums_equal_the_brute_force_definition():
+    rng = np.random.default_rng(3)
+    found = 0
+    for case in range(12):
+        nd = int(rng.integers(2, 5))
+        docs = related_docs(rng, nd, int(rng.integers(30, 90)), 0.08, records=int(rng.integers(1, 3)), with_n=case % 3 == 0)
+        min_len = int(rng.integers(1, 7))
+        for rc in (False, True):
+            res = ro.build(docs, min_len=min_len, revcomp=rc)
+            assert res["mums"] == ro.brute_force_mums(res["text"], res["doc_start"], min_len), (case, rc)
+            found += len(res["mums"])
+    assert found > 40
+    # and both suffix sorters agree
+    text, _ = ro.build_text(related_docs(rng, 3, 3000, 0.02))
+    assert ro.suffix_array(text) == sorted(range(len(text)), key=lambda i: text[i:])
+
+
+def test_oracle_thresholds_equal_the_helpers_definition():
+    """tests/helpers._index_from_bwt_lcp (used by the query tests since round 1) takes the same minimum."""
+    rng = np.random.default_rng(4)
+    res = ro.build(related_docs(rng, 3, 400, 0.03), min_len=10)
+    bwt = np.frombuffer(res["bwt"], np.uint8)
+    lcp = np.array(res["lcp"], np.int64)
+    n = len(bwt)
+    heads = np.flatnonzero(np.concatenate(([True], bwt[1:] != bwt[:-1])))
+    ends = np.append(heads[1:], n) - 1
+    expect = np.zeros(len(heads), np.int64)
+    last = {}
+    for j, c in enumerate(bwt[heads]):
+        if c in last:
+            seg = lcp[ends[last[c]] + 1:heads[j] + 1]
+            expect[j] = ends[last[c]] + 1 + int(np.argmin(seg))
+        last[c] = j
+    assert res["thr"] == expect.tolist()
+
+
+def compare(pkg, docs, min_len, revcomp, label):
+    res = ro.build(docs, min_len=min_len, revcomp=revcomp)
+    got = pkg.rlbwt_from_text(res["text"], res["doc_start"], min_mum=min_len)
+    assert got["n"] == len(res["text"]), label
+    assert got["heads"].tolist() == res["heads"], label
+    assert got["lens"].tolist() == res["lens"], label
+    assert got["thr"].tolist() == res["thr"], (label, np.flatnonzero(got["thr"] != np.array(res["thr"], np.uint64))[:5])
+    assert list(zip(got["mum_len"].tolist(), got["mum_pos"].tolist())) == res["mums"], label
+    return res, got
+
+
+def emu_env():
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    return dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+
+
+def test_emulated_construction_matches_oracle():
+    """The product's construction (HIP sources under the SIMT emulator + ASan; rocPRIM's sorts and
+    scans replaced by <algorithm>) == the oracle."""
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-C", emu, "libcolbwt_emu.so"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(HERE, "test_rlbwt.py"), "emu"], env=emu_env(),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "RLBWT-EMU-OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def emu_main():
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    pkg.LIB_PATH = os.path.join(HERE, "emu", "libcolbwt_emu.so")
+    rng = np.random.default_rng(21)
+    compare(pkg, [[b"GATTACA"], [b"GATTACCGATAACA"]], 3, False, "survey")
+    compare(pkg, [[b"A"], [b"A"]], 1, False, "tiny")
+    for k in range(5):
+        nd = int(rng.integers(1, 5))
+        docs = related_docs(rng, nd, int(rng.integers(40, 700)), 0.04, records=int(rng.integers(1, 3)), with_n=k == 2)
+        compare(pkg, docs, int(rng.integers(1, 12)), bool(k & 1), f"random{k}")
+    # a very repetitive text: many doubling rounds
+    compare(pkg, [[b"ACACACAC" * 40], [b"ACACACAC" * 40 + b"G"]], 5, False, "repeats")
+    print("RLBWT-EMU-OK")
+
+
+@pytest.mark.gpu
+def test_gpu_construction_matches_oracle(pkg):
+    rng = np.random.default_rng(8)
+    compare(pkg, [[b"GATTACA"], [b"GATTACCGATAACA"]], 3, False, "survey")
+    compare(pkg, [[b"A"], [b"A"]], 1, False, "tiny")
+    compare(pkg, [[b"ACACACAC" * 500], [b"ACACACAC" * 500 + b"G"]], 5, False, "repeats")
+    total = 0
+    for k in range(8):
+        nd = int(rng.choice([1, 2, 3, 8, 33]))
+        docs = related_docs(rng, nd, int(rng.integers(500, 60_000 // nd + 600)), 0.01, records=int(rng.integers(1, 4)), with_n=k % 3 == 0)
+        res, got = compare(pkg, docs, int(rng.choice([5, 12, 20])), bool(k & 1), f"random{k}")
+        total += len(res["mums"])
+    assert total > 50
+    # one larger text: 4 x 250 kbp with reverse complements (2 Mbp, > 15 doubling rounds not needed: random)
+    docs = related_docs(rng, 4, 250_000, 0.005)
+    res, got = compare(pkg, docs, 20, True, "large")
+    assert len(res["mums"]) > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_chain_from_fasta_to_query(pkg, oracle, tmp_path):
+    """build_rlbwt -> col_split -> build_col_bwt -> pml_query from FASTA files, every intermediate
+    file equal to the oracle chain's (rlbwt_oracle -> colsplit_oracle -> builder restatement ->
+    query oracle)."""
+    rng = np.random.default_rng(17)
+    docs = related_docs(rng, 5, 6000, 0.01, records=2)
+    paths = []
+    for d, records in enumerate(docs):
+        p = str(tmp_path / f"g{d}.fa")
+        with open(p, "wb") as f:
+            for k, rec in enumerate(records):
+                f.write(b">doc%d_%d\n" % (d, k))
+                for a in range(0, len(rec), 70):
+                    f.write(rec[a:a + 70] + b"\n")
+        paths.append(p)
+    prefix = str(tmp_path / "idx.fa")
+    lst = str(tmp_path / "list.txt")
+    open(lst, "w").write("".join(f"{p} {k + 1}\n" for k, p in enumerate(paths)))
+    exe = lambda name: os.path.join(ROOT, "col-bwt_amd", name)
+    out = subprocess.run([exe("build_rlbwt"), "-r", "-l", "20", "-i", lst, "-o", prefix], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    res = ro.build(docs, min_len=20, revcomp=True)
+    assert len(res["mums"]) > 20
+    for ext, want in zip((".bwt.heads", ".bwt.len", ".thr_pos", ".col_mums"), ro.file_bytes(res, len(docs))):
+        assert open(prefix + ext, "rb").read() == want, ext
+    out = subprocess.run([exe("col_split"), "-m", "tunnels", "-s", "2", prefix], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    heads, lens = np.array(res["heads"], np.uint8), np.array(res["lens"], np.uint64)
+    mlen = np.array([m[0] for m in res["mums"]], np.uint64)
+    mpos = np.array([m[1] for m in res["mums"]], np.uint64)
+    epos, eids, en, stats = oracle.col_split(heads, lens, mlen, mpos, len(docs), "tunnels", 2)
+    n = len(res["text"])
+    raw = np.fromfile(prefix + ".col_runs", np.uint64)
+    assert raw[0] == n == en
+    assert np.array_equal(np.flatnonzero(np.unpackbits(raw[1:].view(np.uint8), bitorder="little")[:n]), epos)
+    assert np.array_equal(np.fromfile(prefix + ".col_ids", np.uint8), eids)
+    out = subprocess.run([exe("build_col_bwt"), prefix], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    image = open(prefix + ".col_pml", "rb").read()
+    assert image == oracle.build_col_pml(heads, lens, eids, epos, np.array(res["thr"], np.uint64)).tobytes()
+    reads = helpers.reads_from_text(res["text"], 400, (30, 300), 0.02, seed=3)
+    bases, off = helpers.concat_reads(reads)
+    ep, ec = oracle.OracleIndex(image).query_batch(bases, off)
+    tbl = pkg.ColPml.load(prefix)
+    p, c, _ = tbl.query_batch(bases, off)
+    tbl.close()
+    assert np.array_equal(p, ep) and np.array_equal(c, ec) and (ec > 0).any()
+    # PMLs of error-free stretches grow to the read's length (a real BWT: matches are found)
+    assert int(ep.max()) >= 100
+    # the launcher's `build` (the reference's command line, col-bwt.py:209-222) leaves the same index
+    outp = str(tmp_path / "launched")
+    out = subprocess.run([sys.executable, exe("col-bwt"), "build", "-r", "-l", "20", "-m", "tunnels", "-s", "2", "-o", outp] + paths,
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert open(outp + ".col_pml", "rb").read() == image
+    assert not os.path.exists(outp + ".fa.col_mums")           # intermediates removed without --keep
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "emu":
+    emu_main()
