@@ -102,6 +102,40 @@ def test_oracle_thresholds_equal_the_helpers_definition():
     assert res["thr"] == expect.tolist()
 
 
+def test_construction_fails_loudly_without_a_device_and_on_bad_text(pkg, tmp_path):
+    """No CPU fallback: argument and format errors first (they need no device), then NO_DEVICE."""
+    with pytest.raises(pkg.ColbwtError) as e:
+        pkg.rlbwt_from_text(b"ACGT\x01", [0])                       # no final 0
+    assert e.value.code == -3
+    with pytest.raises(pkg.ColbwtError) as e:
+        pkg.rlbwt_from_text(b"AC\x00GT\x01\x00", [0])                # a 0 inside
+    assert e.value.code == -3
+    with pytest.raises(pkg.ColbwtError) as e:
+        pkg.rlbwt_from_text(b"ACGT\x01ACGT\x01\x00", [0, 7, 5])       # document starts must ascend
+    assert e.value.code == -1
+    with pytest.raises(pkg.ColbwtError) as e:
+        pkg.rlbwt_from_fastas([str(tmp_path / "missing.fa")], out_prefix=str(tmp_path / "x"))
+    assert e.value.code == -2
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    with pytest.raises(pkg.ColbwtError) as e:
+        pkg.rlbwt_from_fastas([str(empty)], out_prefix=str(tmp_path / "x"))
+    assert e.value.code == -2 and "no record" in str(e.value)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(pkg.ColbwtError) as e:
+            pkg.rlbwt_from_text(b"ACGT\x01ACGA\x01\x00", [0, 5])
+        assert e.value.code == -4
+    exe = os.path.join(ROOT, "col-bwt_amd", "build_rlbwt")
+    out = subprocess.run([exe, "a.fa"], capture_output=True, text=True)              # no -o
+    assert out.returncode == 1 and "usage" in out.stderr
+    out = subprocess.run([exe, "-o", str(tmp_path / "x"), str(tmp_path / "missing.fa")], capture_output=True, text=True)
+    assert out.returncode == 1 and "cannot open" in out.stderr
+    launcher = subprocess.run([sys.executable, os.path.join(ROOT, "col-bwt_amd", "col-bwt"), "build", "-o", str(tmp_path / "y")],
+                              capture_output=True, text=True)
+    assert launcher.returncode == 1 and "required" in launcher.stdout
+
+
 def compare(pkg, docs, min_len, revcomp, label):
     res = ro.build(docs, min_len=min_len, revcomp=revcomp)
     got = pkg.rlbwt_from_text(res["text"], res["doc_start"], min_mum=min_len)
