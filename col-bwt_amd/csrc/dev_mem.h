@@ -10,7 +10,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 namespace colbwt {
 
@@ -58,6 +60,26 @@ inline void dev_free(void *p, uint64_t bytes) {
     DevBudget *b = current_budget();
     if (b) b->used = b->used > bytes ? b->used - bytes : 0;
 }
+
+// COLBWT_LOAD_TIMING=1: the stages of an index open with their wall times on stderr (the device is
+// synchronised at every lap, so the times are the stages' own).
+struct LoadClock {
+    bool on;
+    double t_prev;
+    static double now() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + ts.tv_nsec * 1e-9;
+    }
+    LoadClock() : on(getenv("COLBWT_LOAD_TIMING") != nullptr), t_prev(now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const double t = now();
+        fprintf(stderr, "[colbwt load] %-36s %8.3f s\n", what, t - t_prev);
+        t_prev = t;
+    }
+};
 
 // Owner of one device allocation.
 class DevPtr {

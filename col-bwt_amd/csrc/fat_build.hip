@@ -282,12 +282,15 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
     const uint32_t sigma = T1.sigma;
     PlainLevel cur{};
     PlainBuffers cur_buf;
+    LoadClock clock;
     {
         const SrcL1 s1{T1, chars};
         const int rc = refine_plain(s1, T1.r, T1.n, cur, cur_buf, err);    // level 2 (cuts at thresholds too)
         if (rc != COLBWT_OK) return rc;
     }
+    clock.lap("  refinement level 2");
     source_done();
+    clock.lap("  one-step tables freed");
     for (int level = 3; level <= K; ++level) {
         PlainLevel next{};
         PlainBuffers next_buf;
@@ -301,6 +304,7 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
         cur_buf.O = std::move(next_buf.O);
         cur_buf.meta = std::move(next_buf.meta);
         cur_buf.thr = std::move(next_buf.thr);
+        clock.lap("  refinement level (3..K)");
     }
 
     const uint32_t r = cur.r;
@@ -343,16 +347,20 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
 
     SK_TRY(buf.claim.alloc((uint64_t)kFatClaimSets * kFatClaimBlocks * sizeof(uint32_t)));
     out.claim = buf.claim.as<uint32_t>();
+    clock.lap("  characters, jump tables");
     SK_TRY(buf.lines.alloc(((uint64_t)r + 1) * kFatRowBytes));
+    clock.lap("  lines allocated");
     uint8_t *const d_lines = buf.lines.as<uint8_t>();
     SK_TRY(hipMemset(d_lines + (uint64_t)r * kFatRowBytes, 0, kFatRowBytes));
     hipLaunchKernelGGL(fat_pack_kernel<K>, dim3(nblocks), dim3(256), 0, 0, cur, out, d_lines);
     SK_TRY(hipGetLastError());
     SK_TRY(hipStreamSynchronize(0));
     out.lines = d_lines;
+    clock.lap("  lines packed");
     buf.idx = std::move(cur_buf.idx);
     buf.thr = std::move(cur_buf.thr);
     cur_buf.release();          // I, O, meta: only the pack pass read them
+    clock.lap("  level arrays freed");
     return COLBWT_OK;
 }
 

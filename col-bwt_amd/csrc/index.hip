@@ -115,6 +115,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     release();
     (void)hipGetLastError();   // a stale error of an earlier attempt must not fail this one
     BudgetScope budget;
+    LoadClock clock;
     device_ = device;
     bwt_r_ = bwt_r;
 
@@ -128,6 +129,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
     HIP_TRY(d_idx_.alloc((r + 1) * sizeof(uint64_t)));
     HIP_TRY(d_thr_.alloc(r * sizeof(uint64_t)));
     HIP_TRY(d_cmap_.alloc(256));
+    clock.lap("one-step tables allocated, zeroed");
 
     // ---- upload packed rows chunk by chunk and re-lay them out on the device
     RelayoutReport h_report{};
@@ -152,6 +154,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         }
         HIP_TRY(hipMemcpy(&h_report, d_report, sizeof(h_report), hipMemcpyDeviceToHost));
     }
+    clock.lap("rows uploaded and re-laid out");
     if (h_report.flags) {
         err = "corrupt .col_pml near row " + std::to_string(h_report.first_bad) + ":";
         if (h_report.flags & 1u) err += " idx not strictly increasing;";
@@ -220,10 +223,12 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         HintChars hc{};
         for (uint32_t c = 0; c < 256; ++c)
             if (cmap[c] != kAbsent && cmap[c] < 8) hc.c[cmap[c]] = (uint8_t)c;
+        clock.lap("jump tables");
         launch_hints(tbl_, d_rows_.as<uint4>(), hc, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(0));
         tbl_.use_hints = 1;
+        clock.lap("threshold hints");
 
         // ---- optional K-step layout on top (sk_layout.h).  The one-step tables are only the
         // source of the refinement: they are freed as soon as the last pass that reads them is
@@ -245,6 +250,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
             layout_ = layout;
         }
     }
+    clock.lap("K-step / line-row layout");
     peak_device_bytes_ = budget.b.peak;
     return COLBWT_OK;
 }
