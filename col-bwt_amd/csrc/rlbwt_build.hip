@@ -129,11 +129,28 @@ __global__ void run_chars_kernel(const uint8_t *bwt, const uint32_t *start, uint
     }
 }
 
+// Minimum of (lcp << 32 | position) over every block of kThrBlock positions: the long segments of
+// the threshold pass (a rare character -- separators, N -- has runs hundreds of millions of
+// positions apart, and ONE wavefront scanning such a gap took seconds) step over whole blocks.
+constexpr uint32_t kThrBlock = 2048;
+
+__global__ void block_min_kernel(const uint32_t *lcp, uint64_t n, uint64_t n_blocks, uint64_t *block_min) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)kTB + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * kTB) >> 6;
+    for (uint64_t b = wave; b < n_blocks; b += n_waves) {
+        const uint64_t lo = b * kThrBlock, hi = min(lo + kThrBlock, n);
+        uint64_t best = ~0ull;
+        for (uint64_t k = lo + lane; k < hi; k += 64) best = min(best, ((uint64_t)lcp[k] << 32) | k);
+        for (int d = 32; d; d >>= 1) best = min(best, (uint64_t)__shfl_xor((unsigned long long)best, d));
+        if (lane == 0) block_min[b] = best;
+    }
+}
+
 // by_char: run numbers sorted stably by character.  One wavefront per entry t: the run j = by_char[t]
 // and the previous run of its character p = by_char[t-1]; first minimum of lcp over
 // [start[p+1], start[j]].
 __global__ void threshold_kernel(const uint32_t *by_char, const uint8_t *head, const uint32_t *start, const uint32_t *lcp,
-                                 uint64_t r, uint32_t *thr) {
+                                 const uint64_t *block_min, uint64_t r, uint32_t *thr) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * (uint64_t)kTB + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * kTB) >> 6;
     for (uint64_t t = wave; t < r; t += n_waves) {
@@ -142,9 +159,15 @@ __global__ void threshold_kernel(const uint32_t *by_char, const uint8_t *head, c
             if (lane == 0) thr[j] = 0;
             continue;
         }
-        const uint64_t lo = start[by_char[t - 1] + 1], hi = start[j];   // the previous run is not the last one
-        uint64_t best = ~0ull;                                           // (lcp << 32 | position): first minimum
-        for (uint64_t k = lo + lane; k <= hi; k += 64) best = min(best, ((uint64_t)lcp[k] << 32) | k);
+        const uint64_t lo = start[by_char[t - 1] + 1], hi = (uint64_t)start[j] + 1;   // [lo, hi); the previous run is not the last one
+        uint64_t best = ~0ull;                                                        // (lcp << 32 | position): first minimum
+        uint64_t b_lo = (lo + kThrBlock - 1) / kThrBlock, b_hi = hi / kThrBlock;      // whole blocks [b_lo, b_hi)
+        if (b_lo >= b_hi) b_lo = b_hi = hi / kThrBlock + 1;                           // none: one direct scan
+        const uint64_t head_end = min(hi, b_lo * kThrBlock), tail_begin = max(lo, b_hi * kThrBlock);
+        for (uint64_t k = lo + lane; k < head_end; k += 64) best = min(best, ((uint64_t)lcp[k] << 32) | k);
+        for (uint64_t b = b_lo + lane; b < b_hi; b += 64) best = min(best, block_min[b]);
+        if (head_end < hi)
+            for (uint64_t k = max(tail_begin, head_end) + lane; k < hi; k += 64) best = min(best, ((uint64_t)lcp[k] << 32) | k);
         for (int d = 32; d; d >>= 1) best = min(best, (uint64_t)__shfl_xor((unsigned long long)best, d));
         if (lane == 0) thr[j] = (uint32_t)best;
     }
@@ -228,6 +251,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
     if (n >= 0xffffffffull) { err = "text of " + std::to_string(n) + " characters: the suffix numbers are 32-bit"; return COLBWT_ERR_FORMAT; }
     if (n_docs > kMaxDocs) { err = "more than " + std::to_string(kMaxDocs) + " documents"; return COLBWT_ERR_FORMAT; }
     if (text[n - 1] != 0) { err = "the text must end with its only 0 byte"; return COLBWT_ERR_FORMAT; }
+    LoadClock clock;
     std::vector<uint32_t> seps, docs(n_docs);
     for (uint64_t i = 0; i < n; ++i) {
         if (text[i] <= 1) seps.push_back((uint32_t)i);
@@ -253,6 +277,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
         err = "out of device memory for the suffix sort of " + std::to_string(n) + " characters";
         return COLBWT_ERR_NOMEM;
     }
+    clock.lap("rlbwt: text checked, buffers allocated");
     RB_TRY(hipMemcpy(d_text.get(), text, n, hipMemcpyHostToDevice));
     hipcub::DoubleBuffer<uint64_t> keys(d_key[0].as<uint64_t>(), d_key[1].as<uint64_t>());
     hipcub::DoubleBuffer<uint32_t> sa(d_sa[0].as<uint32_t>(), d_sa[1].as<uint32_t>());
@@ -301,6 +326,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
         end_bit = 2 * bits;
         h *= 2;
     }
+    clock.lap("rlbwt: suffix array");
     const uint32_t *d_sa_final = sa.Current();
     uint32_t *d_sa_spare = sa.Alternate();
 
@@ -311,7 +337,9 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
     for (int j = 0; j < lv.count; ++j) lv.rank[j] = levels[j].as<uint32_t>();
     hipLaunchKernelGGL(lcp_kernel, dim3(grid), dim3(kTB), 0, 0, T, d_sa_final, n, lv, d_lcp);
     RB_TRY(hipDeviceSynchronize());
+    clock.lap("rlbwt: LCP");
     levels.clear();                                     // the rank arrays are no longer needed
+    clock.lap("rlbwt:   rank arrays freed");
     uint8_t *d_bwt = reinterpret_cast<uint8_t *>(keys.Current());          // key buffers are free now: bwt | flags
     uint8_t *d_flag = d_bwt + n;
     uint32_t *d_start = reinterpret_cast<uint32_t *>(keys.Alternate());    // run starts, then run-sized arrays behind
@@ -322,6 +350,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
                                          d_groups.as<unsigned long long>(), (size_t)n));
     unsigned long long r = 0;
     RB_TRY(hipMemcpy(&r, d_groups.get(), 8, hipMemcpyDeviceToHost));
+    clock.lap("rlbwt:   BWT, run starts");
 
     // thresholds
     DevPtr d_head, d_head2, d_id, d_id2, d_thr;
@@ -347,8 +376,17 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
                                                   d_id2.as<uint32_t>(), (size_t)r, 0, 8));
         RB_TRY(hipDeviceSynchronize());
     }
-    hipLaunchKernelGGL(threshold_kernel, dim3(grid_for(r * 64)), dim3(kTB), 0, 0, p_id2, p_head, d_start, d_lcp, (uint64_t)r, p_thr);
+    clock.lap("rlbwt:   runs sorted by character");
+    const uint64_t n_thr_blocks = (n + kThrBlock - 1) / kThrBlock;
+    DevPtr d_block_min;
+    if (no(d_block_min.alloc(8 * n_thr_blocks))) { err = "out of device memory"; return COLBWT_ERR_NOMEM; }
+    uint64_t *p_block_min = d_block_min.as<uint64_t>();
+    hipLaunchKernelGGL(block_min_kernel, dim3(grid_for(n_thr_blocks * 64)), dim3(kTB), 0, 0, d_lcp, n, n_thr_blocks, p_block_min);
+    hipLaunchKernelGGL(threshold_kernel, dim3(grid_for(r * 64)), dim3(kTB), 0, 0, p_id2, p_head, d_start, d_lcp, p_block_min, (uint64_t)r,
+                       p_thr);
+    RB_TRY(hipDeviceSynchronize());
 
+    clock.lap("rlbwt: runs, thresholds");
     out.n = n;
     out.heads.resize(r);
     out.lens.resize(r);
@@ -364,6 +402,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
         }
     }
 
+    clock.lap("rlbwt: runs copied back");
     // multi-MUMs
     out.mum_len.clear();
     out.mum_pos.clear();
@@ -397,6 +436,7 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
     }
     RB_TRY(hipDeviceSynchronize());
     RB_TRY(hipGetLastError());
+    clock.lap("rlbwt: multi-MUMs");
     return COLBWT_OK;
 }
 
@@ -437,11 +477,15 @@ extern "C" int colbwt_rlbwt_build_files(const char *const *fastas, uint32_t n_fi
     }
     std::vector<uint8_t> text;
     std::vector<uint64_t> doc_start;
+    colbwt::LoadClock clock;
     if (!colbwt::text_from_fastas(paths, revcomp != 0, text, doc_start, g_rlbwt_err)) return COLBWT_ERR_IO;
+    clock.lap("rlbwt: FASTA files read");
     colbwt_rlbwt *h = new colbwt_rlbwt;
     h->n_docs = n_files;
     int rc = colbwt::rlbwt_from_text(text.data(), text.size(), doc_start.data(), n_files, min_mum, device, h->res, g_rlbwt_err);
+    clock.lap("rlbwt: construction");
     if (rc == COLBWT_OK && out_prefix && !colbwt::write_rlbwt_files(out_prefix, h->res, n_files, g_rlbwt_err)) rc = COLBWT_ERR_IO;
+    clock.lap("rlbwt: files written");
     if (rc != COLBWT_OK || !out) delete h; else *out = h;
     return rc;
 }

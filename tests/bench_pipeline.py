@@ -78,6 +78,9 @@ def main():
         if r.returncode != 0:
             sys.exit(f"{name} failed: {r.stdout[-2000:]}{r.stderr[-2000:]}")
         print(f"{name}: {out[name + '_s']} s", file=sys.stderr, flush=True)
+        for line in r.stderr.splitlines():          # COLBWT_LOAD_TIMING=1: the stage's own breakdown
+            if line.startswith("[colbwt load]"):
+                print("   " + line, file=sys.stderr, flush=True)
     out["mums"] = (os.path.getsize(prefix + ".col_mums") - 5) // 10
     image = open(prefix + ".col_pml", "rb").read()
     t0 = time.time()

@@ -176,6 +176,8 @@ def emu_main():
         compare(pkg, docs, int(rng.integers(1, 12)), bool(k & 1), f"random{k}")
     # a very repetitive text: many doubling rounds
     compare(pkg, [[b"ACACACAC" * 40], [b"ACACACAC" * 40 + b"G"]], 5, False, "repeats")
+    # long gaps between the runs of a rare character: the threshold pass steps over whole 2048-position blocks
+    compare(pkg, related_docs(rng, 2, 5200, 0.02, with_n=True), 8, False, "blocks")
     print("RLBWT-EMU-OK")
 
 
