@@ -194,6 +194,19 @@ def test_gpu_construction_matches_oracle(pkg):
         res, got = compare(pkg, docs, int(rng.choice([5, 12, 20])), bool(k & 1), f"random{k}")
         total += len(res["mums"])
     assert total > 50
+    # many short documents: windows of 300 suffixes, a document bit set of ten words
+    base = rng.choice(ACGT, size=90)
+    docs = []
+    for _ in range(300):                                             # substitutions in the first half only: the rest is shared
+        s = base.copy()
+        at = rng.integers(0, 45, size=2)
+        s[at] = rng.choice(ACGT, size=2)
+        docs.append([bytes(s)])
+    res, got = compare(pkg, docs, 6, False, "many_docs")
+    assert len(res["mums"]) >= 1 and max(m[0] for m in res["mums"]) >= 45
+    with pytest.raises(pkg.ColbwtError) as e:                       # more documents than the scan's bit set holds
+        pkg.rlbwt_from_text(b"A\x01" * 4097 + b"\x00", list(range(0, 2 * 4097, 2)))
+    assert e.value.code == -3
     # one larger text: 4 x 250 kbp with reverse complements (2 Mbp, > 15 doubling rounds not needed: random)
     docs = related_docs(rng, 4, 250_000, 0.005)
     res, got = compare(pkg, docs, 20, True, "large")
