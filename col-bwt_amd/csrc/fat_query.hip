@@ -187,7 +187,8 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
     rc.commit();
     done = !rc.enter_chunk(plan, claim);
 
-    OutAccRun acc;
+    OutAccPml acc_pml;
+    OutAccCid acc_cid;
     LaneWindow win;
     win.init(rc.off + rc.k - 1);
     uint4 (*const my_win)[64] = s_win[wave];
@@ -253,8 +254,10 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
         // All of it has landed at the one wait below.
         if constexpr (!kWide) {
             if (chunk_end) {                                 // what the finished chunk's last trips pushed
-                acc.flush_group((uint16_t *)pml, cid, end_gl);
-                acc.flush_rest((uint16_t *)pml, cid, end_gl);
+                acc_pml.flush_group((uint16_t *)pml, end_gl);
+                acc_pml.flush_rest((uint16_t *)pml, end_gl);
+                acc_cid.flush_group(cid, end_gl);
+                acc_cid.flush_rest(cid, end_gl);
             }
         }
         FAT_CLOCK(6);
@@ -355,7 +358,8 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
                             cid[g - consumed + 1 + e] = (uint8_t)(ids >> (8 * e));
                         }
                     } else {
-                        acc.push_run(consumed, l_new, (uint32_t)ids, (uint32_t)(ids >> 32));
+                        acc_pml.push_run(consumed, l_new);
+                        acc_cid.push_run(consumed, (uint32_t)ids, (uint32_t)(ids >> 32));
                     }
                 }
                 k -= consumed;
@@ -388,8 +392,10 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
         // ---- (5) the output groups the trip completed, all lanes' at once; the staged rows are read,
         // their LDS serves as the parking area
         wave_sync();
-        if constexpr (!kWide)
-            acc.flush_group_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
+        if constexpr (!kWide) {
+            acc_pml.flush_group_wave((uint16_t *)pml, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
+            acc_cid.flush_group_wave(cid, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
+        }
         wave_sync();   // the next trip overwrites s_jx and the staged rows
         FAT_CLOCK(3);
 #ifdef COLBWT_COUNT_TRIPS
