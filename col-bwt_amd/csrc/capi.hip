@@ -318,6 +318,9 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
             (void)hipGetLastError();                                                            \
+            /* nothing of this call may still be running when the caller gets its arrays (and the \
+               next caller the staging buffers) back: kernel and copies are drained first */      \
+            if (stream) (void)hipStreamSynchronize(stream);                                     \
             return bad(e_ == hipErrorOutOfMemory ? COLBWT_ERR_NOMEM : COLBWT_ERR_HIP,           \
                        std::string(#expr) + ": " + hipGetErrorString(e_));                      \
         }                                                                                       \

@@ -25,7 +25,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <queue>
 #include <string>
 #include <vector>
 
@@ -260,62 +259,75 @@ bool build_fl(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens, FLHo
 
 uint8_t bin_id(uint64_t id) { return (uint8_t)(id >= 256 ? id % 255 + 1 : id); }   // col_split.hpp:222-224
 
-// find_col_runs (col_split.hpp:258-342) over the marked positions in ascending order.
+// What col_split::find_col_runs (col_split.hpp:258-342) computes, derived here as two passes
+// over sorted arrays instead of the reference's heap of open intervals.
+//
+// A marked position k opens the interval [pos[k], pos[k] + heights[k]) carrying ids[k].  The
+// reference's rule for which id is "in force" along the BWT only ever looks at moments where at
+// most one interval is open, so all it needs of the open set is its SIZE and, when that is one,
+// WHICH interval it is -- a counter and the XOR of the open intervals' numbers give both:
+//
+//   pass 1 (col events, ascending):  intervals are closed in order of (end, start), always before
+//     the next one opens; a close at x with exactly one interval left that reaches beyond x hands
+//     x to that interval's id, a close that leaves none open hands x to id 0 unless an interval
+//     opens at x itself (or x is the end of the BWT); an interval that opens alone takes its start
+//     for its id when the id is non-zero.
+//   pass 2 (merge with the BWT run heads):  every run head becomes a sub-run start carrying the id
+//     in force there; a head that coincides with a col event is represented by the event.
 void find_col_runs(const FLHost &t, const std::vector<uint64_t> &pos, const std::vector<uint8_t> &ids,
                    const std::vector<uint16_t> &heights, std::vector<uint64_t> &split_pos, std::vector<uint8_t> &split_ids) {
     split_pos.clear();
     split_ids.clear();
-    if (pos.empty()) return;                                   // :259-261
+    const size_t m = pos.size();
+    if (m == 0) return;                                        // nothing marked: no files' worth of output (:259-261)
     const uint64_t n = t.n, r = t.idx.size() - 1;
-    struct interval {
-        uint64_t start, end;
-        uint8_t id;
-        bool operator>(const interval &o) const { return end > o.end || (end == o.end && start > o.start); }
-    };
-    std::priority_queue<interval, std::vector<interval>, std::greater<interval>> open;
-    uint64_t run_cursor = 1;
-    auto run_select = [&](uint64_t k) { return k <= r ? t.L_head[k - 1] : n; };
-    uint64_t curr_bwt_pos = run_select(1);
-    uint8_t last_id = 0;
-    auto mark = [&](uint64_t p, uint8_t id) {                  // col_runs[p] = 1; add_col_run_id(id)
-        split_pos.push_back(p);
-        split_ids.push_back(id);
-    };
-    auto update_bwt_pos = [&](uint64_t idx, uint8_t id) {      // :296-308
-        while (run_cursor <= r && curr_bwt_pos < idx) {
-            mark(curr_bwt_pos, last_id);
-            ++run_cursor;
-            curr_bwt_pos = run_select(run_cursor);
-        }
-        if (curr_bwt_pos == idx) {
-            ++run_cursor;
-            curr_bwt_pos = run_select(run_cursor);
-        }
-        last_id = id;
-    };
-    auto update_col_ranges = [&](uint64_t idx) {               // :310-325
-        while (!open.empty() && open.top().end <= idx) {
-            const interval e = open.top();
-            open.pop();
-            if (open.size() == 1 && open.top().end > e.end) {
-                update_bwt_pos(e.end, open.top().id);
-                mark(e.end, open.top().id);
-            } else if (open.empty() && e.end < idx) {
-                update_bwt_pos(e.end, 0);
-                mark(e.end, 0);
-            }
+
+    // ---- pass 1
+    std::vector<uint64_t> ends(m);
+    for (size_t k = 0; k < m; ++k) ends[k] = pos[k] + heights[k];
+    std::vector<uint64_t> by_end(m);                           // interval numbers by (end, start); starts ascend with k
+    for (size_t k = 0; k < m; ++k) by_end[k] = k;
+    std::stable_sort(by_end.begin(), by_end.end(), [&](uint64_t a, uint64_t b) { return ends[a] < ends[b]; });
+    std::vector<std::pair<uint64_t, uint8_t>> events;          // (position, id taking over there)
+    events.reserve(2 * m);
+    size_t n_open = 0, closed = 0;
+    uint64_t open_xor = 0;                                     // XOR of the open intervals' numbers
+    auto close_up_to = [&](uint64_t x, size_t opened) {        // every OPENED interval ending at or before x
+        while (closed < m && ends[by_end[closed]] <= x && by_end[closed] < opened) {
+            const uint64_t e = by_end[closed++];
+            --n_open;
+            open_xor ^= e;
+            if (n_open == 1 && ends[open_xor] > ends[e]) events.emplace_back(ends[e], ids[open_xor]);
+            else if (n_open == 0 && ends[e] < x) events.emplace_back(ends[e], (uint8_t)0);
         }
     };
-    for (size_t i = 0; i < pos.size(); ++i) {                  // :328-340
-        update_col_ranges(pos[i]);
-        open.push({pos[i], pos[i] + heights[i], ids[i]});
-        if (open.size() == 1 && ids[i] > 0) {
-            update_bwt_pos(pos[i], ids[i]);
-            mark(pos[i], ids[i]);
-        }
+    for (size_t k = 0; k < m; ++k) {
+        close_up_to(pos[k], k);
+        ++n_open;
+        open_xor ^= k;
+        if (n_open == 1 && ids[k] > 0) events.emplace_back(pos[k], ids[k]);
     }
-    update_col_ranges(n);                                      // :341-342
-    update_bwt_pos(n, 0);
+    close_up_to(n, m);
+
+    // ---- pass 2
+    split_pos.reserve(events.size() + r);
+    split_ids.reserve(events.size() + r);
+    uint64_t head = 0;                                         // next BWT run not yet written
+    uint8_t in_force = 0;
+    auto heads_before = [&](uint64_t x) {
+        for (; head < r && t.L_head[head] < x; ++head) {
+            split_pos.push_back(t.L_head[head]);
+            split_ids.push_back(in_force);
+        }
+    };
+    for (const auto &ev : events) {
+        heads_before(ev.first);
+        if (head < r && t.L_head[head] == ev.first) ++head;
+        in_force = ev.second;
+        split_pos.push_back(ev.first);
+        split_ids.push_back(ev.second);
+    }
+    heads_before(n);
 }
 
 int col_split_run(const uint8_t *heads, uint64_t n_heads, const uint64_t *lens, const uint64_t *mum_len, const uint64_t *mum_pos,

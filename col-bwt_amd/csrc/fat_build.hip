@@ -345,8 +345,6 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
     out.idx = cur.idx;
     out.thr = cur.thr;
 
-    SK_TRY(buf.claim.alloc((uint64_t)kFatClaimSets * kFatClaimBlocks * sizeof(uint32_t)));
-    out.claim = buf.claim.as<uint32_t>();
     clock.lap("  characters, jump tables");
     SK_TRY(buf.lines.alloc(((uint64_t)r + 1) * kFatRowBytes));
     clock.lap("  lines allocated");
@@ -400,11 +398,11 @@ __global__ __launch_bounds__(256) void fat_synth_reads_kernel(FatView V, uint64_
 }  // namespace
 
 void FatBuffers::release() {
-    for (DevPtr *p : {&lines, &chr, &idx, &thr, &next, &prev, &claim}) p->reset();
+    for (DevPtr *p : {&lines, &chr, &idx, &thr, &next, &prev}) p->reset();
 }
 
 uint64_t FatBuffers::bytes() const {
-    return lines.bytes() + chr.bytes() + idx.bytes() + thr.bytes() + next.bytes() + prev.bytes() + claim.bytes();
+    return lines.bytes() + chr.bytes() + idx.bytes() + thr.bytes() + next.bytes() + prev.bytes();
 }
 
 bool fat_steps_supported(int steps) {

@@ -38,6 +38,32 @@
 //   entries beyond K are zero.
 // Side arrays (cold: rare characters, read sampler, load-time kernels):
 //   chr[r] u8, idx[r+1] u64 (idx[r] = n), thr[r] u64, next_tbl / prev_tbl per 256-row block.
+//
+// ---- line rows with MISMATCH LINES (COLBWT_LAYOUT_LINE_ROWS_MISMATCH_LINES; slot_line0 != 0) ----
+// Where threshold_step goes on a mismatch is ONE position p_c for every position of an ORIGINAL
+// row (a row of the file, cut at the thresholds that fall inside it: call it an origin row) and a
+// character c -- the in-row slots above store that fact once per REFINED row (5.25 per origin row
+// at K = 8), which is why they have room for one outcome only: "the base after the mismatch
+// matches".  When it does not (60 % of the mismatches on the C2 workload) the lane lands on the
+// next row only to find another mismatch: in a stretch of consecutive mismatches every base costs
+// a line fill.  Here the fact is stored once per (origin row, character) in a table of its own,
+// and each entry has room for EVERY outcome of the base after the mismatch:
+//   * rows keep [0, 80) as above (the read sampler and the side arrays are shared) and hold, in
+//     place of the slots, RHO[1..8] = the origin row met after a - 1 LF steps and VAL = which of
+//     its three mismatch entries exist; a read base that differs from CH[a] sends the lane to the
+//     entry (RHO[a], slot) directly -- the next trip fetches the entry's line, not a row;
+//   * a mismatch entry (64 bytes, two per line, behind the rows in the same allocation: line
+//     slot_line0 + e / 2, e = 3 * rho + slot) resolves the mismatching base AND the base after it
+//     whatever it is: q1 = LF(p_c), the character / col id met there, and for each of the four
+//     things the next base can do -- match, or mismatch on one of the three slot characters of
+//     q1's origin row -- the exact landing after that base, the character and col id met there,
+//     its origin row and which of ITS entries exist.  If the base after those two mismatches as
+//     well, the lane goes from entry to entry: a stretch of mismatches costs a line fill per two
+//     bases, and a trip never ends on a row just to learn that it mismatches.
+// Entry dwords: [0] J1 | [1] P1 | t1 << 16 | d1 << 24 | [2..5] J[0..3] | [6..9] rho[0..3] |
+//   [10..11] P[0..3] halfwords | [12] ch[0..3] bytes | [13] cid[0..3] bytes |
+//   [14] v1 | vo[0] << 4 | vo[1] << 8 | vo[2] << 12 | vo[3] << 16 (3 valid bits each) | [15] 0.
+//   outcome 0 = the next base matches t1; outcome 1 + s = it is slot character s of q1's origin row.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -57,6 +83,11 @@ constexpr uint32_t kFatCh = 0, kFatCid = 8, kFatLen = 16, kFatFlags = 18, kFatCu
                    kFatSlot0 = 80, kFatSlotBytes = 16;
 // inside a slot
 constexpr uint32_t kFatSlotP = 8, kFatSlotCh2 = 12, kFatSlotCid2 = 13;
+// rows of the mismatch-line variant: valid bits of the origin row met after a - 1 steps at bits
+// 3 (a - 1) of the three bytes at kFatVal; RHO[a] dwords at kFatRho
+constexpr uint32_t kFatVal = 28, kFatRho = 80;
+// a mismatch entry
+constexpr uint32_t kMisBytes = 64, kMisJ1 = 0, kMisP1 = 1, kMisJ = 2, kMisRho = 6, kMisP = 10, kMisCh = 12, kMisCid = 13, kMisVal = 14;
 
 struct FatTable {
     const uint8_t *lines;     // r rows of 128 bytes (+ one zero row)
@@ -72,9 +103,9 @@ struct FatTable {
     uint32_t nblk;
     uint32_t steps;           // K
     uint32_t top4;            // the four most frequent characters, byte k = dense index k
-    uint32_t *claim;          // kFatClaimSets x kFatClaimBlocks chunk counters of the query's persistent workgroups
+    uint32_t slot_line0;      // mismatch-line variant: line number (128-byte units of `lines`) of entry 0; 0 = in-row slots
+    uint32_t n_rho;           // origin rows (entries: 3 per origin row)
 };
-constexpr uint32_t kFatClaimSets = 16, kFatClaimBlocks = 4096;
 
 // byte / halfword / dword k of a row image held as dwords
 __device__ __forceinline__ uint32_t fat_byte(const uint32_t *w, uint32_t off) { return (w[off >> 2] >> (8 * (off & 3u))) & 0xFFu; }

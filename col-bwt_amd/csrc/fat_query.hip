@@ -27,7 +27,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <atomic>
 
 #include "device_layout.h"
 #include "fat_layout.h"
@@ -85,7 +84,7 @@ __device__ __forceinline__ uint32_t matching_top_bytes(uint64_t x) {   // bytes 
 // 150 bp reads) nor the launch (which ends with its slowest lane) is held up by slow reads.
 // Chunks are CLAIMED: every workgroup owns an equal share of the batch (a share is thousands of
 // reads: shares differ by a fraction of a percent in work), and inside it a lane's first chunk is
-// its own number and every further one comes from a counter in LDS -- a counter in HBM shared by
+// its own number and every further one comes from the workgroup's counter in LDS -- a counter in HBM shared by
 // the whole grid serialises (150 M claims/s measured: the 10 M single-read claims of a C2 batch
 // took longer than the query).  The claim is made one chunk ahead of need, so the offsets of the
 // claimed chunk are in registers when the lane gets there.  The bulk of a share goes out in
@@ -166,20 +165,25 @@ struct ReadCursor {
 template <int K, typename PmlT>
 __global__ __launch_bounds__(kQueryBlock)
 void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off,
-                      uint64_t n_reads, uint32_t big_reads, uint32_t tail_permille, uint32_t *__restrict__ claim_base,
+                      uint64_t n_reads, uint32_t big_reads, uint32_t tail_permille,
                       PmlT *__restrict__ pml, uint8_t *__restrict__ cid) {
     constexpr bool kWide = sizeof(PmlT) == 4;
     __shared__ uint4 s_stage[kWaves][8][64];       // per wave: instruction q's 64 x 16 bytes
     __shared__ uint4 s_win[kWaves][4][64];         // read bytes (lane_io.h LaneWindow)
-    // 48 KB in all: three workgroups (12 waves) per CU -- the registers of the collector allow no
-    // more.  The rows the lanes want are handed to their groups through the last 256 bytes of the
-    // wave's own stage area, which the trip's last DMA (q = 7) fills only after every lane has
-    // read them; the chunk counter of the workgroup lives in global memory.
+    __shared__ uint32_t s_claim;                   // the workgroup's chunk counter (ChunkPlan)
+    // 48 KB (+ the counter) in all: three workgroups (12 waves) per CU -- the registers of the
+    // collector allow no more.  The rows the lanes want are handed to their groups through the last
+    // 256 bytes of the wave's own stage area, which the trip's last DMA (q = 7) fills only after
+    // every lane has read them.  The chunk counter lives in LDS and is zeroed by the workgroup
+    // itself: a launch owns no state outside its arguments, so any number of launches may overlap
+    // on one index (other streams, other host threads).
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, g8 = lane & ~7u, p = lane & 7u;
     uint32_t *const s_jx = reinterpret_cast<uint32_t *>(&s_stage[wave][7][48]);   // 64 dwords
     ChunkPlan plan;
     plan.init(n_reads, big_reads, tail_permille);
-    uint32_t *const claim = claim_base + blockIdx.x;
+    if (threadIdx.x == 0) s_claim = 0;
+    __syncthreads();
+    uint32_t *const claim = &s_claim;
     ReadCursor rc;
     bool done;
     rc.c_next = threadIdx.x;                          // the first chunk is the lane's own number
@@ -430,7 +434,7 @@ template <int K, typename PmlT>
 void launch_typed(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                   PmlT *d_pml, uint8_t *d_cid, hipStream_t stream) {
     const uint64_t want_blocks = (n_reads + kQueryBlock - 1) / kQueryBlock;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(want_blocks, resident_blocks<K, PmlT>()), kFatClaimBlocks);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want_blocks, resident_blocks<K, PmlT>());
     // Reads per bulk chunk: a chunk ends with a ragged flush of the collector, so it should hold a
     // few reads -- but no more than a sixth of a lane's share of the BASES, or a few lanes end up
     // with most of a workgroup's work (1 M reads of 10 kbp are five reads per lane: chunks of eight
@@ -445,13 +449,8 @@ void launch_typed(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_r
         if (v >= 1 && v <= 1024) big = (uint32_t)v;
         if (const char *c = strchr(e, ',')) tail_permille = (uint32_t)std::min(1000, std::max(0, atoi(c + 1)));
     }
-    // one chunk counter per workgroup, from a ring of counter sets so that launches that overlap
-    // (several host threads or streams on one index) do not share them
-    static std::atomic<uint32_t> next_set{0};
-    uint32_t *claims = T.claim + (size_t)(next_set.fetch_add(1) % kFatClaimSets) * kFatClaimBlocks;
-    (void)hipMemsetAsync(claims, 0, blocks * sizeof(uint32_t), stream);
     hipLaunchKernelGGL((fat_query_kernel<K, PmlT>), dim3(blocks), dim3(kQueryBlock), 0, stream, T, d_bases, d_read_off, n_reads,
-                       big, tail_permille, claims, d_pml, d_cid);
+                       big, tail_permille, d_pml, d_cid);
 }
 
 template <int K>

@@ -1,7 +1,7 @@
 // pml_query -- drop-in command line of the reference's query executable
 // (src/pml_query.cpp:92-143) over the MI355X engine (libcolbwt.so).
 //
-//   pml_query [-v] [-l] [-b] [-d DEVICE[,DEVICE..]] -p <reads.fa|fq[.gz]> <index_prefix>
+//   pml_query [-v] [-l] [-b|-B] [-d DEVICE[,DEVICE..]] -p <reads.fa|fq[.gz]> <index_prefix>
 //
 // Same getopt string as the reference ("rvlN:p:m:s:o:", common.hpp:231; the
 // build-side options are accepted and ignored) plus -d and -b.  Reads
@@ -10,7 +10,8 @@
 //   -d 0,1,..  replicates the table on several devices and shards every batch of reads over
 //              them (a device may be listed twice);
 //   -b         writes <pattern>.pml.bin / <pattern>.cid.bin instead (the containers `col-bwt
-//              query` produces; Movi-like, unverified: include/colbwt.h).
+//              query` produces; Movi-like, unverified: include/colbwt.h);
+//   -B         writes both kinds, text first, from one load of the index.
 //
 // Deliberate deviations:
 //   * a missing index / pattern argument or an unreadable file is fatal (exit 1);
@@ -35,13 +36,14 @@ static double now_s() {
 
 int main(int argc, char *const argv[]) {
     std::string pattern;
-    bool verbose = false, binary = false;
+    bool verbose = false, binary = false, text = true;
     std::vector<int> devices;
     int c;
-    while ((c = getopt(argc, argv, "rvlN:p:m:s:o:d:b")) != -1) {
+    while ((c = getopt(argc, argv, "rvlN:p:m:s:o:d:bB")) != -1) {
         switch (c) {
             case 'v': verbose = true; break;
-            case 'b': binary = true; break;
+            case 'b': binary = true; text = false; break;
+            case 'B': binary = true; text = true; break;
             case 'p': pattern = optarg; break;
             case 'd':
                 for (const char *q = optarg; *q;) {
@@ -57,7 +59,7 @@ int main(int argc, char *const argv[]) {
     }
     if (argc != optind + 1) {
         fprintf(stderr, "[ERROR]: Invalid number of arguments\n");
-        fprintf(stderr, "usage: pml_query [-v] [-l] [-b] [-d device[,device..]] -p <pattern FASTA/FASTQ[.gz]> <index_prefix>\n");
+        fprintf(stderr, "usage: pml_query [-v] [-l] [-b|-B] [-d device[,device..]] -p <pattern FASTA/FASTQ[.gz]> <index_prefix>\n");
         return 1;
     }
     const std::string prefix = argv[optind];
@@ -89,9 +91,20 @@ int main(int argc, char *const argv[]) {
 
     printf("[INFO] Computing PML Queries: \n");
     colbwt_stats st;
-    const std::string pml_name = pattern + (binary ? ".pml.bin" : ".pml"), cid_name = pattern + (binary ? ".cid.bin" : ".cid");
-    const int qrc = binary ? colbwt_query_file_binary(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st)
-                           : colbwt_query_file(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st);
+    std::string pml_name, cid_name;
+    int qrc = COLBWT_OK;
+    if (text) {                                            // pml_query.cpp:124-125
+        pml_name = pattern + ".pml";
+        cid_name = pattern + ".cid";
+        qrc = colbwt_query_file(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st);
+        if (qrc == COLBWT_OK && binary)
+            printf("[INFO] \tPMLs written to: %s\n[INFO] \tCIDs written to: %s\n", pml_name.c_str(), cid_name.c_str());
+    }
+    if (qrc == COLBWT_OK && binary) {
+        pml_name = pattern + ".pml.bin";
+        cid_name = pattern + ".cid.bin";
+        qrc = colbwt_query_file_binary(idx, pattern.c_str(), pml_name.c_str(), cid_name.c_str(), 0, &st);
+    }
     if (qrc != COLBWT_OK) {
         fprintf(stderr, "[ERROR]: %s\n", colbwt_last_error());
         colbwt_index_close(idx);

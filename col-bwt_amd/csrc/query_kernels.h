@@ -71,7 +71,7 @@ int build_sk(const DevTable &T, const HintChars &chars, int steps, SKTable &out,
 
 // Device allocations of a line-row table (fat_layout.h).
 struct FatBuffers {
-    DevPtr lines, chr, idx, thr, next, prev, claim;
+    DevPtr lines, chr, idx, thr, next, prev;
     uint64_t bytes() const;
     void release();
 };

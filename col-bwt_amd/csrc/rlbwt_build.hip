@@ -117,14 +117,23 @@ __global__ void bwt_kernel(const uint8_t *T, const uint32_t *sa, uint64_t n, uin
     }
 }
 
+// A run is a maximal stretch of equal characters AS THE CONSUMERS SEE THEM: the reference folds
+// every byte <= 1 to the terminator when it reads .bwt.heads (col_bwt.hpp:167-171,
+// FL_table.hpp:102-104) and hands out one threshold per maximal group of equal folded characters
+// (read_thresholds, col_bwt.hpp:446-451).  The final 0 and the separators 1 are therefore ONE
+// class here: where the 0 touches a run of 1s (the suffix-array neighbours of suffix 0 are other
+// record starts -- always so when documents share a prefix) they are one run with head 1, and the
+// k-th threshold written belongs to the k-th group the builder forms.
+__device__ __forceinline__ uint8_t fold_sep(uint8_t c) { return c <= 1 ? (uint8_t)1 : c; }
+
 __global__ void run_flags_kernel(const uint8_t *bwt, uint64_t n, uint8_t *flag) {
     for (uint64_t k = blockIdx.x * (uint64_t)kTB + threadIdx.x; k < n; k += (uint64_t)gridDim.x * kTB)
-        flag[k] = k == 0 || bwt[k] != bwt[k - 1];
+        flag[k] = k == 0 || fold_sep(bwt[k]) != fold_sep(bwt[k - 1]);
 }
 
 __global__ void run_chars_kernel(const uint8_t *bwt, const uint32_t *start, uint64_t r, uint8_t *head, uint32_t *id) {
     for (uint64_t j = blockIdx.x * (uint64_t)kTB + threadIdx.x; j < r; j += (uint64_t)gridDim.x * kTB) {
-        head[j] = bwt[start[j]];
+        head[j] = fold_sep(bwt[start[j]]);
         id[j] = (uint32_t)j;
     }
 }
@@ -202,31 +211,47 @@ __global__ void cap_lcp_kernel(const uint32_t *sa, const uint32_t *seps, uint32_
     }
 }
 
-__global__ void mum_kernel(const uint32_t *sa, const uint32_t *lcp, const uint8_t *bwt, const uint32_t *doc_start,
-                           uint32_t n_docs, uint64_t n, uint32_t min_len, uint8_t *flag, uint32_t *mum_len) {
+// Minimum of lcp over every window of w consecutive entries in O(1) per window: the array is cut
+// into blocks of w entries, pre[k] = minimum from the start of k's block to k, suf[k] = minimum from
+// k to the end of its block; a window [a, a + w) spans at most two blocks, so its minimum is
+// min(suf[a], pre[a + w - 1]).  One thread per block (w entries each).
+__global__ void window_min_kernel(const uint32_t *lcp, uint64_t n, uint32_t w, uint32_t *pre, uint32_t *suf) {
+    const uint64_t n_blocks = (n + w - 1) / w;
+    for (uint64_t b = blockIdx.x * (uint64_t)kTB + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * kTB) {
+        const uint64_t lo = b * w, hi = min(lo + w, n);
+        uint32_t m = ~0u;
+        for (uint64_t k = lo; k < hi; ++k) { m = min(m, lcp[k]); pre[k] = m; }
+        m = ~0u;
+        for (uint64_t k = hi; k > lo; --k) { m = min(m, lcp[k - 1]); suf[k - 1] = m; }
+    }
+}
+
+// A multi-MUM starts at suffix-array rank i when the n_docs suffixes from there share at least
+// min_len characters (the minimum of the n_docs - 1 capped LCPs between them: one window lookup),
+// more than with the suffix on either side, are not all preceded by the same character, and come
+// one from every document.  The tests run from the cheapest to the dearest: the per-document walk
+// (a binary search per suffix, 512 bytes of flags per thread) only happens for the windows that
+// passed everything else -- a handful per thousand positions even on hundreds of similar genomes.
+__global__ void mum_kernel(const uint32_t *sa, const uint32_t *lcp, const uint32_t *pre, const uint32_t *suf, const uint8_t *bwt,
+                           const uint32_t *doc_start, uint32_t n_docs, uint64_t n, uint32_t min_len, uint8_t *flag, uint32_t *mum_len) {
     for (uint64_t i = blockIdx.x * (uint64_t)kTB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kTB) {
         flag[i] = 0;
         if (i + n_docs > n) continue;
-        uint32_t m = ~0u;
-        bool ok = true;
-        for (uint32_t t = 1; t < n_docs; ++t) {
-            const uint32_t v = lcp[i + t];
-            if (v < min_len) { ok = false; break; }
-            m = min(m, v);
-        }
-        if (!ok || lcp[i] >= m || (i + n_docs < n && lcp[i + n_docs] >= m)) continue;
+        const uint32_t m = min(suf[i + 1], pre[i + n_docs - 1]);          // lcp[i + 1 .. i + n_docs - 1]
+        if (m < min_len || lcp[i] >= m || (i + n_docs < n && lcp[i + n_docs] >= m)) continue;
+        const uint8_t c0 = bwt[i];
+        bool differ = c0 <= 1;
+        for (uint32_t t = 1; t < n_docs && !differ; ++t) differ = bwt[i + t] != c0;
+        if (!differ) continue;
         uint32_t seen[kMaxDocs / 32];
         for (uint32_t w = 0; w < (n_docs + 31) / 32; ++w) seen[w] = 0;
-        const uint8_t c0 = bwt[i];
-        bool differ = false;
+        bool ok = true;
         for (uint32_t t = 0; t < n_docs; ++t) {
             const uint32_t d = upper_bound_u32(doc_start, n_docs, sa[i + t]) - 1;
             if (seen[d >> 5] >> (d & 31) & 1) { ok = false; break; }
             seen[d >> 5] |= 1u << (d & 31);
-            const uint8_t c = bwt[i + t];
-            differ |= c != c0 || c <= 1;
         }
-        if (!ok || !differ) continue;
+        if (!ok) continue;
         flag[i] = 1;
         mum_len[i] = m;
     }
@@ -336,6 +361,15 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
     lv.count = (int)levels.size();
     for (int j = 0; j < lv.count; ++j) lv.rank[j] = levels[j].as<uint32_t>();
     hipLaunchKernelGGL(lcp_kernel, dim3(grid), dim3(kTB), 0, 0, T, d_sa_final, n, lv, d_lcp);
+    // A pattern never holds a separator, so what lies behind one cannot decide between two runs:
+    // thresholds and multi-MUMs both work on the LCPs cut at the first separator (all separators are
+    // the same byte 1: the raw LCP of `T\1ACG..` and `T\1ACG..` runs on into the next records).
+    DevPtr d_seps;
+    if (no(d_seps.alloc(4 * seps.size()))) { err = "out of device memory"; return COLBWT_ERR_NOMEM; }
+    RB_TRY(hipMemcpy(d_seps.get(), seps.data(), 4 * seps.size(), hipMemcpyHostToDevice));
+    const uint32_t *p_seps = d_seps.as<uint32_t>();
+    const uint32_t n_seps = (uint32_t)seps.size();
+    hipLaunchKernelGGL(cap_lcp_kernel, dim3(grid), dim3(kTB), 0, 0, d_sa_final, p_seps, n_seps, n, d_lcp);
     RB_TRY(hipDeviceSynchronize());
     clock.lap("rlbwt: LCP");
     levels.clear();                                     // the rank arrays are no longer needed
@@ -407,15 +441,17 @@ int rlbwt_from_text(const uint8_t *text, uint64_t n, const uint64_t *doc_start, 
     out.mum_len.clear();
     out.mum_pos.clear();
     if (n_docs >= 2) {
-        DevPtr d_seps, d_docs;
-        if (no(d_seps.alloc(4 * seps.size())) || no(d_docs.alloc(4 * n_docs))) { err = "out of device memory"; return COLBWT_ERR_NOMEM; }
-        RB_TRY(hipMemcpy(d_seps.get(), seps.data(), 4 * seps.size(), hipMemcpyHostToDevice));
+        DevPtr d_docs, d_pre, d_suf;
+        if (no(d_docs.alloc(4 * n_docs)) || no(d_pre.alloc(4 * n)) || no(d_suf.alloc(4 * n))) { err = "out of device memory"; return COLBWT_ERR_NOMEM; }
         RB_TRY(hipMemcpy(d_docs.get(), docs.data(), 4 * n_docs, hipMemcpyHostToDevice));
-        const uint32_t *p_seps = d_seps.as<uint32_t>(), *p_docs = d_docs.as<uint32_t>();
-        const uint32_t n_seps = (uint32_t)seps.size(), min_len = (uint32_t)std::min<uint64_t>(min_mum, 0xffffffffu);
-        hipLaunchKernelGGL(cap_lcp_kernel, dim3(grid), dim3(kTB), 0, 0, d_sa_final, p_seps, n_seps, n, d_lcp);
+        const uint32_t *p_docs = d_docs.as<uint32_t>();
+        const uint32_t min_len = (uint32_t)std::min<uint64_t>(min_mum, 0xffffffffu);
+        uint32_t *p_pre = d_pre.as<uint32_t>(), *p_suf = d_suf.as<uint32_t>();
+        const uint32_t window = n_docs - 1;
+        hipLaunchKernelGGL(window_min_kernel, dim3(grid_for((n + window - 1) / window)), dim3(kTB), 0, 0, d_lcp, n, window, p_pre, p_suf);
         uint32_t *d_mlen = d_sa_spare;
-        hipLaunchKernelGGL(mum_kernel, dim3(grid), dim3(kTB), 0, 0, d_sa_final, d_lcp, d_bwt, p_docs, n_docs, n, min_len, d_flag, d_mlen);
+        hipLaunchKernelGGL(mum_kernel, dim3(grid), dim3(kTB), 0, 0, d_sa_final, d_lcp, p_pre, p_suf, d_bwt, p_docs, n_docs, n, min_len, d_flag,
+                           d_mlen);
         tb = tmp_bytes;
         uint32_t *d_pos = d_start;                     // run starts are on the host already
         RB_TRY(hipcub::DeviceSelect::Flagged(d_tmp.get(), tb, hipcub::CountingInputIterator<uint32_t>(0), d_flag, d_pos,

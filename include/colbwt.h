@@ -144,7 +144,12 @@ int colbwt_query_batch_u32(colbwt_index *idx, const uint8_t *bases, const uint64
  * pml_bytes is 2 or 4 (2 needs every read <= 65535 bases).  `hip_stream` is a
  * hipStream_t (NULL = default stream); the call is asynchronous unless
  * `stats` is non-NULL, in which case it records HIP events on the stream,
- * synchronises it and fills kernel_ms. */
+ * synchronises it and fills kernel_ms.
+ * Concurrency contract: a launch keeps no state outside its arguments (the
+ * kernels' work counters live in LDS), so ANY number of calls may be in flight
+ * on one index at once -- from any host threads, on any streams -- as long as
+ * their output buffers are distinct; there is no bound to respect and nothing
+ * to serialise (tests/test_gpu_parity.py queues 48 launches on 24 streams). */
 int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off,
                         uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes,
                         uint8_t *d_cid, void *hip_stream, colbwt_stats *stats);
@@ -153,7 +158,10 @@ int colbwt_query_device(colbwt_index *idx, const uint8_t *d_bases, const uint64_
  * n_reads entries, nullable) lists the read indices by decreasing length, so the
  * 64 lanes of a wave walk reads of similar length.  Results are identical with
  * or without it (each read's values only depend on that read); the host entry
- * points build the order themselves when a batch is ragged. */
+ * points build the order themselves when a batch is ragged.  d_order is
+ * ADVISORY: the K-step and one-step layouts assign lanes by it, the line-row
+ * layout (COLBWT_LAYOUT_LINE_ROWS, the default) ignores it -- its persistent
+ * lanes claim chunks of consecutive reads and balance ragged batches themselves. */
 int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const uint64_t *d_read_off,
                                 uint64_t n_reads, uint64_t n_bases, void *d_pml, int pml_bytes,
                                 uint8_t *d_cid, const uint32_t *d_order, void *hip_stream,
@@ -233,8 +241,13 @@ const char *colbwt_col_split_error(void);
  * restated here and UNVERIFIED against it ("parity unpinned"):
  *   text        every record of every file as it is + separator 1 (+ its reverse complement + 1 when
  *               `revcomp`; one document per file), then one final 0; suffixes compare byte-wise
+ *   runs        maximal stretches of equal characters with every byte <= 1 (the final 0, the
+ *               separators) taken as ONE character, head 1 -- the class the reference folds them to
+ *               when it reads .bwt.heads (col_bwt.hpp:167-171) and groups thresholds by
+ *               (col_bwt.hpp:446-451): entry k of .thr_pos belongs to group k of the builder
  *   threshold   first position of the minimum LCP in (end of the previous run of the character,
- *               head of this run]; 0 for a character's first run
+ *               head of this run]; 0 for a character's first run.  LCPs are cut at the first
+ *               separator: what lies behind one can never be matched by a pattern
  *   multi-MUM   num_docs consecutive suffixes, one from every document, that share >= min_mum
  *               characters (never across a separator), more than with either neighbouring suffix,
  *               and are not all preceded by the same character; position = suffix-array rank of

@@ -11,7 +11,8 @@ own code only consumes these files.  What is restated here is therefore the publ
 the files (BWT of the concatenated documents, min-LCP thresholds as col_bwt.hpp:531-574 uses them,
 multi-MUM = maximal match occurring exactly once in every document) with this repository's
 conventions for what the formats leave open (include/colbwt.h): separators 1, a final 0, byte-wise
-suffix order, first minimum for ties.  Everything is written for clarity, independently of the
+suffix order, runs of the folded characters (bytes <= 1 are one class), LCPs cut at separators,
+first minimum for ties.  Everything is written for clarity, independently of the
 product's algorithms (plain sorting, Kasai, direct character comparison); `brute_force_mums`
 does not use a suffix array at all.
 """
@@ -78,9 +79,13 @@ def lcp_array(text, sa):
 
 
 def rlbwt(text, sa):
+    """Runs of the characters as the consumers see them: bytes <= 1 (the final 0, the separators)
+    are one class, the terminator 1 (col_bwt.hpp:167-171, FL_table.hpp:102-104), so that the k-th
+    run is the k-th group read_thresholds (col_bwt.hpp:446-451) gives a threshold to."""
     bwt = bytes(text[i - 1] for i in sa)            # text[-1] for i == 0: the final 0
     heads, lens = [], []
     for c in bwt:
+        c = max(c, 1)
         if heads and heads[-1] == c:
             lens[-1] += 1
         else:
@@ -89,9 +94,14 @@ def rlbwt(text, sa):
     return bwt, heads, lens
 
 
+def capped_lcp(text, sa):
+    """LCP of neighbouring suffixes cut at the first separator: what a pattern can tell apart."""
+    return [0] + [_match_len(text, sa[k - 1], sa[k]) for k in range(1, len(text))]
+
+
 def thresholds(heads, lens, lcp):
-    """Per run: first position of the minimum LCP in (end of the previous run of its character,
-    its head]; 0 for a character's first run."""
+    """Per run: first position of the minimum (separator-capped) LCP in (end of the previous run
+    of its character, its head]; 0 for a character's first run."""
     start, thr, last_end = 0, [], {}
     for c, ln in zip(heads, lens):
         if c in last_end:
@@ -125,7 +135,7 @@ def multi_mums(text, sa, doc_start, min_len):
     n, nd = len(text), len(doc_start)
     if nd < 2:
         return []
-    adj = [0] + [_match_len(text, sa[k - 1], sa[k]) for k in range(1, n)]
+    adj = capped_lcp(text, sa)
     out = []
     for i in range(0, n - nd + 1):
         inner = min(adj[i + 1:i + nd])
@@ -177,7 +187,7 @@ def build(docs, min_len=20, revcomp=False):
     lcp = lcp_array(text, sa)
     bwt, heads, lens = rlbwt(text, sa)
     return dict(text=text, doc_start=doc_start, sa=sa, lcp=lcp, bwt=bwt, heads=heads, lens=lens,
-                thr=thresholds(heads, lens, lcp), mums=multi_mums(text, sa, doc_start, min_len))
+                thr=thresholds(heads, lens, capped_lcp(text, sa)), mums=multi_mums(text, sa, doc_start, min_len))
 
 
 def file_bytes(res, n_docs):

@@ -4,7 +4,9 @@ failure paths the capacity configuration depends on.
   C3  the per-rank shard of the 8-GPU run is the C2 batch (same index, 10 M x 150 bp per GPU):
       covered by test_gpu_parity.py::test_full_scale_properties and named here.
   C4  2e8-row index, >= 100 k reads of ~10 kbp (+-20 % length jitter, 5 % substitutions), all
-      four HBM layouts, device entry point with and without the length order, host entry point.
+      four HBM layouts, device entry point with and without the length order, host entry point;
+      and the configuration's own size, 1 M reads (1e10 bases), on line rows: two runs and the
+      three-step layout compared on the device, the oracle on the first, middle and last reads.
   C5  capacity: the largest indices one MI355X takes -- 1e9 rows opened with AUTO (line rows do
       not fit: three-step rows, ~130 GB resident), 1.7e9 rows where the three-step refinement passes 2^32-2 rows and
       AUTO must settle for two-step rows -- plus the HBM-budget fallback and what a failed open
@@ -127,6 +129,73 @@ def test_c4_long_reads_all_layouts(pkg, oracle, c2_image):
         del p1, c1, d_bases, d_off
         tbl.close()
     assert host_result
+
+
+def test_c4_at_baseline_size_one_million_long_reads(pkg, oracle, c2_image):
+    """BASELINE configs[3] at its own size: 1 M reads of 8-12 kbp (1e10 bases, 5 % substitutions,
+    backward walks on the 2e8-row index) on line rows -- five reads per persistent lane, so every
+    lane claims further chunks from its workgroup's counter and the last tenth of every share goes
+    out read by read (fat_query.hip ChunkPlan; the 100 k-read case above never gets there).
+    Two runs are compared ON THE DEVICE, then with the three-step layout's run on the same
+    buffers; the oracle (col_bwt.hpp:498-529 restated) checks >= 50 Mbase taken from the FIRST,
+    MIDDLE and LAST reads of the batch -- the tail is where single-read chunks are claimed."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_reads = int(os.environ.get("COLBWT_TEST_C4_READS", "1000000"))
+    m_max, chunk = 12_000, 20_000
+    rng = np.random.default_rng(14)
+    lens_np = rng.integers(8_000, m_max + 1, size=n_reads)
+    off_np = np.zeros(n_reads + 1, np.int64)
+    off_np[1:] = np.cumsum(lens_np)
+    nb = int(off_np[-1])
+    _free_hbm()
+    tbl = pkg.ColPml.from_bytes(c2_image, layout=4)
+    assert tbl.info().layout == 4
+    d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
+    d_off = torch.from_numpy(off_np).to(dev)
+    d_fixed = torch.zeros(chunk * m_max + 128, dtype=torch.uint8, device=dev)
+    d_foff = torch.zeros(chunk + 1, dtype=torch.int64, device=dev)
+    for lo in range(0, n_reads, chunk):                      # ragged suffixes of fixed-length walks, chunk by chunk
+        k = min(chunk, n_reads - lo)
+        tbl.synth_reads_device(k, m_max, 50, 500 + lo // chunk, d_fixed.data_ptr(), d_foff.data_ptr())
+        part, part_off = _ragged_suffixes(torch, d_fixed, k, m_max, torch.from_numpy(lens_np[lo:lo + k]))
+        assert int(part_off[-1]) == off_np[lo + k] - off_np[lo]
+        d_bases[off_np[lo]:off_np[lo + k]] = part[:int(part_off[-1])]
+        del part, part_off
+    del d_fixed, d_foff
+    torch.cuda.synchronize()
+
+    def run(t):
+        p = torch.full((nb + 64,), -1, dtype=torch.int16, device=dev)
+        c = torch.full((nb + 64,), 0xEE, dtype=torch.uint8, device=dev)
+        st = t.query_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, nb, p.data_ptr(), c.data_ptr(), 2, 0, timed=True)
+        assert (p[nb:] == -1).all() and (c[nb:] == 0xEE).all()           # nothing written past the batch
+        return p[:nb], c[:nb], st.kernel_ms
+    p1, c1, ms1 = run(tbl)
+    p2, c2, _ = run(tbl)
+    assert torch.equal(p1, p2) and torch.equal(c1, c2)
+    del p2, c2
+    print(f"C4 at BASELINE size: {n_reads} reads, {nb} bases, line rows {ms1:.1f} ms = {nb / ms1 / 1e6:.1f} Gbase/s")
+    # the oracle on the first, middle and last reads
+    ref = oracle.OracleIndex(c2_image)
+    per = max(1, min(n_reads // 3, 1_800))
+    checked = 0
+    for lo in (0, (n_reads - per) // 2, n_reads - per):
+        b0, b1 = int(off_np[lo]), int(off_np[lo + per])
+        ep, ec = ref.query_batch(d_bases[b0:b1].cpu().numpy(), (off_np[lo:lo + per + 1] - b0).astype(np.uint64), threads=16)
+        assert np.array_equal(p1[b0:b1].cpu().numpy().view(np.uint16), ep), f"PML differs from the oracle in reads {lo}.."
+        assert np.array_equal(c1[b0:b1].cpu().numpy(), ec), f"col ids differ from the oracle in reads {lo}.."
+        assert 0.05 < float((ep == 0).mean()) < 0.7
+        checked += b1 - b0
+    assert checked >= min(50_000_000, nb * 0.9)
+    tbl.close()
+    _free_hbm()
+    tbl3 = pkg.ColPml.from_bytes(c2_image, layout=3)
+    assert tbl3.info().layout == 3
+    p3, c3, ms3 = run(tbl3)
+    assert torch.equal(p1, p3) and torch.equal(c1, c3), "three-step rows and line rows disagree"
+    print(f"  three-step rows {ms3:.1f} ms = {nb / ms3 / 1e6:.1f} Gbase/s")
+    tbl3.close()
 
 
 def _oracle_sample_check(pkg, oracle_index, tbl, n_reads, m, seed, sample):

@@ -315,8 +315,29 @@ def test_cli_pml_query_and_col_bwt_launcher(golden_dir, tmp_path):
         assert out.returncode == 0, out.stdout + out.stderr
         for ext in (".pml", ".cid"):
             assert open(str(fa) + ext, "rb").read() == open(os.path.join(golden_dir, "kat_d.fa" + ext), "rb").read()
+    # the launcher also leaves the artefacts the reference's `query` leaves (col-bwt.py:194,198):
+    # PATTERN.split.pml.bin / .split.cid.bin, here links to the containers; `view` turns them back
+    # into the golden text
+    for kind, width in (("pml", 2), ("cid", 1)):
+        split = str(fa) + f".split.{kind}.bin"
+        assert os.path.islink(split) and os.path.exists(split) and os.path.exists(str(fa) + f".{kind}.bin")
+        view = subprocess.run([sys.executable, launcher, "view", split, "-o", str(d / f"view.{kind}")], capture_output=True, text=True)
+        assert view.returncode == 0, view.stderr
+        assert open(d / f"view.{kind}", "rb").read() == open(os.path.join(golden_dir, f"kat_d.fa.{kind}"), "rb").read()
+    for flag, present, absent in (("-b", (".pml.bin", ".split.pml.bin", ".split.cid.bin"), (".pml", ".cid")),
+                                  ("-t", (".pml", ".cid"), (".pml.bin", ".split.pml.bin"))):
+        d = tmp_path / f"run{flag}"
+        d.mkdir()
+        fa = d / "kat_d.fa"
+        shutil.copy(os.path.join(golden_dir, "kat_d.fa"), fa)
+        out = subprocess.run([sys.executable, launcher, "query", flag, "-p", str(fa), os.path.join(golden_dir, "kat_d")],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert all(os.path.exists(str(fa) + e) for e in present) and not any(os.path.lexists(str(fa) + e) for e in absent)
     bad = subprocess.run([exe, "-p", str(fa), "/nonexistent/prefix"], capture_output=True, text=True)
     assert bad.returncode != 0 and "[ERROR]" in bad.stderr
+    bad = subprocess.run([sys.executable, launcher, "query", "-p", str(fa), "/nonexistent/prefix"], capture_output=True, text=True)
+    assert bad.returncode != 0 and not os.path.lexists(str(fa) + ".split.pml.bin")
 
 
 def test_large_file_parallel_text_formatting(pkg, oracle, tmp_path):
@@ -361,6 +382,41 @@ def test_concurrent_host_threads_share_one_index(pkg, oracle):
     for t in range(4):
         ep, ec = ref.query_batch(*jobs[t], threads=8)
         assert np.array_equal(results[t][0], ep) and np.array_equal(results[t][1], ec)
+
+
+def test_many_overlapping_launches_on_one_index(pkg, oracle):
+    """include/colbwt.h: any number of colbwt_query_device launches may be in flight on one index.
+    48 asynchronous launches on 24 streams (two per stream, nothing waited for in between) against
+    one line-row index, each over a batch of its own large enough to run for a while and to claim
+    chunks from the workgroups' counters; every result equals the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    image = pkg.synth_index(2_000_000, mean_len=8, split_permille=0, seed=42)
+    tbl = pkg.ColPml.from_bytes(image, layout=4)
+    assert tbl.info().layout == 4
+    n_launch, n_streams, n_reads, m = 48, 24, 120_000, 150
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    d_bases = torch.zeros((n_launch, n_reads * m + 128), dtype=torch.uint8, device=dev)
+    d_off = torch.zeros((n_launch, n_reads + 1), dtype=torch.int64, device=dev)
+    d_pml = torch.full((n_launch, n_reads * m + 64), -1, dtype=torch.int16, device=dev)
+    d_cid = torch.full((n_launch, n_reads * m + 64), 0xEE, dtype=torch.uint8, device=dev)
+    s0 = torch.cuda.current_stream().cuda_stream
+    for q in range(n_launch):
+        tbl.synth_reads_device(n_reads, m, 10, 900 + q, d_bases[q].data_ptr(), d_off[q].data_ptr(), s0)
+    torch.cuda.synchronize()
+    for q in range(n_launch):                      # all queued back to back: launches overlap on the device
+        tbl.query_device(d_bases[q].data_ptr(), d_off[q].data_ptr(), n_reads, n_reads * m,
+                         d_pml[q].data_ptr(), d_cid[q].data_ptr(), 2, streams[q % n_streams].cuda_stream)
+    torch.cuda.synchronize()
+    ref = oracle.OracleIndex(image.tobytes())
+    off = d_off[0].cpu().numpy().astype(np.uint64)
+    for q in range(n_launch):
+        bases = d_bases[q, :n_reads * m].cpu().numpy()
+        epml, ecid = ref.query_batch(bases, off, threads=16)
+        assert np.array_equal(d_pml[q, :n_reads * m].cpu().numpy().view(np.uint16), epml), f"launch {q}: PML"
+        assert np.array_equal(d_cid[q, :n_reads * m].cpu().numpy(), ecid), f"launch {q}: col ids"
+        assert (d_pml[q, n_reads * m:] == -1).all() and (d_cid[q, n_reads * m:] == 0xEE).all()
+    tbl.close()
 
 
 def test_open_close_does_not_leak_hbm(pkg):

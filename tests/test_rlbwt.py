@@ -84,11 +84,12 @@ def test_oracle_mums_equal_the_brute_force_definition():
 
 
 def test_oracle_thresholds_equal_the_helpers_definition():
-    """tests/helpers._index_from_bwt_lcp (used by the query tests since round 1) takes the same minimum."""
+    """tests/helpers._index_from_bwt_lcp (used by the query tests since round 1) takes the same minimum --
+    here over the runs of the folded characters and the separator-capped LCPs."""
     rng = np.random.default_rng(4)
     res = ro.build(related_docs(rng, 3, 400, 0.03), min_len=10)
-    bwt = np.frombuffer(res["bwt"], np.uint8)
-    lcp = np.array(res["lcp"], np.int64)
+    bwt = np.maximum(np.frombuffer(res["bwt"], np.uint8), 1)
+    lcp = np.array(ro.capped_lcp(res["text"], res["sa"]), np.int64)
     n = len(bwt)
     heads = np.flatnonzero(np.concatenate(([True], bwt[1:] != bwt[:-1])))
     ends = np.append(heads[1:], n) - 1
@@ -100,6 +101,47 @@ def test_oracle_thresholds_equal_the_helpers_definition():
             expect[j] = ends[last[c]] + 1 + int(np.argmin(seg))
         last[c] = j
     assert res["thr"] == expect.tolist()
+
+
+def _folded_groups(heads):
+    """The groups read_thresholds (col_bwt.hpp:446-451) forms: maximal stretches of equal characters
+    after bytes <= 1 (and >= 0x80) are folded to the terminator (col_bwt.hpp:167-171)."""
+    f = [1 if (c <= 1 or c >= 0x80) else c for c in heads]
+    return [k for k in range(len(f)) if k == 0 or f[k] != f[k - 1]]
+
+
+def test_documents_sharing_a_prefix_get_one_threshold_per_group_of_the_builder(oracle):
+    """The suffix-array neighbours of suffix 0 are other record starts, so when documents share a
+    prefix the final 0 of the BWT touches a run of separators: written as two runs, the builder (which
+    folds both to the terminator and gives the k-th threshold to the k-th GROUP) would hand every later
+    run its predecessor's threshold.  Runs are runs of the folded characters: one threshold per group,
+    and every row of the built index carries its own run's value."""
+    cases = [[[b"ACGTTGCA"], [b"ACGTAGCA"]]]
+    rng = np.random.default_rng(12)
+    cases.append(related_docs(rng, 3, 400, 0.01))
+    for docs in cases:
+        for rc in (False, True):
+            res = ro.build(docs, min_len=4, revcomp=rc)
+            raw_heads = [c for k, c in enumerate(res["bwt"]) if k == 0 or c != res["bwt"][k - 1]]
+            assert len(_folded_groups(raw_heads)) < len(raw_heads)         # the 0 does touch a run of 1s here
+            heads, lens, thr = res["heads"], res["lens"], res["thr"]
+            assert 0 not in heads and len(_folded_groups(heads)) == len(heads) == len(thr)
+            starts = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.uint64)
+            image = oracle.build_col_pml(heads, lens, np.zeros(len(heads), np.uint8), starts, thr)
+            t = helpers.unpack_col_pml(image)
+            assert t["r"] == len(heads) and t["n"] == len(res["text"])
+            assert t["thr"].tolist() == thr and t["idx"].tolist() == starts.tolist()
+
+
+def test_thresholds_ignore_what_lies_behind_a_separator():
+    """All separators are the same byte, so the raw LCP of two suffixes that reach one together runs
+    on into the NEXT records -- context no pattern can match.  The two conventions differ on this
+    text; the files hold the capped one."""
+    docs = [[b"CAT", b"GGGGA"], [b"CAT", b"GGGGC"], [b"TAT", b"GGGGA"]]
+    res = ro.build(docs, min_len=2)
+    raw = ro.thresholds(res["heads"], res["lens"], res["lcp"])
+    assert res["thr"] == ro.thresholds(res["heads"], res["lens"], ro.capped_lcp(res["text"], res["sa"]))
+    assert raw != res["thr"]
 
 
 def test_construction_fails_loudly_without_a_device_and_on_bad_text(pkg, tmp_path):
@@ -270,6 +312,16 @@ def test_gpu_chain_from_fasta_to_query(pkg, oracle, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert open(outp + ".col_pml", "rb").read() == image
     assert not os.path.exists(outp + ".fa.col_mums")           # intermediates removed without --keep
+    # --keep leaves them; a second run then skips the first step unless --force (col-bwt.py:121-135,
+    # 219); --clean removes them whatever --keep says (col-bwt.py:184-186, 223)
+    common = ["-r", "-l", "20", "-m", "tunnels", "-s", "2", "-o", outp] + paths
+    out = subprocess.run([sys.executable, exe("col-bwt"), "build", "--keep"] + common, capture_output=True, text=True)
+    assert out.returncode == 0 and os.path.exists(outp + ".fa.col_mums") and "skipping" not in out.stdout
+    out = subprocess.run([sys.executable, exe("col-bwt"), "build", "--keep"] + common, capture_output=True, text=True)
+    assert out.returncode == 0 and "already found, skipping" in out.stdout
+    out = subprocess.run([sys.executable, exe("col-bwt"), "build", "--keep", "--force", "--clean"] + common, capture_output=True, text=True)
+    assert out.returncode == 0 and "skipping" not in out.stdout and not os.path.exists(outp + ".fa.col_mums")
+    assert open(outp + ".col_pml", "rb").read() == image
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "emu":
