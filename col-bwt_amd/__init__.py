@@ -127,7 +127,8 @@ class ColPml:
 
     @classmethod
     def load(cls, prefix_or_file, device=0, layout=0, devices=None):
-        """layout: 0 = engine default, 1 = one-step rows, 2 / 3 = K-step rows, 4 = line rows (same results)."""
+        """layout: 0 = engine default, 1 = one-step rows, 2 / 3 = K-step rows, 4 = line rows, 5 = line rows with
+        mismatch lines (same results)."""
         h = C.c_void_p()
         if devices is not None:
             dv = (C.c_int * len(devices))(*[int(d) for d in devices])

@@ -30,7 +30,7 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_LINE_ROWS
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_MISMATCH_LINES
 constexpr int kDefaultLineSteps = 8;
 
 // Device buffers, stream and events of one host-entry query, kept with the handle between calls
@@ -287,7 +287,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     // classes is enough: waves only need reads of SIMILAR length side by side).  The line-row
     // kernel balances by itself (persistent lanes claim chunks of reads).
     std::vector<uint32_t> order;
-    if (idx->ix.layout() != COLBWT_LAYOUT_LINE_ROWS && n_reads <= 0xFFFFFFFFull && n_reads > 64 &&
+    if (!idx->ix.line_rows() && n_reads <= 0xFFFFFFFFull && n_reads > 64 &&
         max_len > min_len + (min_len >> 2) + 16) {
         const uint64_t span = max_len - min_len + 1;
         uint32_t shift = 0;
@@ -344,7 +344,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     HOST_HIP(hipMemcpyAsync(d_off, off_src, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     if (d_order) HOST_HIP(hipMemcpyAsync(d_order, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HOST_HIP(hipEventRecord(S.ev[1], stream));
-    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+    if (idx->ix.line_rows())
         launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, n_bases, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
@@ -520,7 +520,7 @@ const char *colbwt_last_error(void) { return g_err.c_str(); }
 
 static int default_layout() {
     const char *e = getenv("COLBWT_LAYOUT");   // override: 1 = one-step, 2 / 3 = K-step rows, 4 = line rows
-    if (e && e[0] >= '1' && e[0] <= '4' && e[1] == 0) return e[0] - '0';
+    if (e && e[0] >= '1' && e[0] <= '5' && e[1] == 0) return e[0] - '0';
     return COLBWT_LAYOUT_DEFAULT_CHOICE;
 }
 
@@ -547,9 +547,10 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     const bool automatic = layout == COLBWT_LAYOUT_AUTO;
     if (automatic) layout = default_layout();
     const int steps = line_rows_steps(layout);
+    const bool steps_given = ((layout >> 8) & 0xFF) != 0 || getenv("COLBWT_LINE_ROWS_STEPS") != nullptr;
     layout &= 0xFF;
-    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_LINE_ROWS) return fail(COLBWT_ERR_ARG, "bad layout");
-    if (layout == COLBWT_LAYOUT_LINE_ROWS && !fat_steps_supported(steps))
+    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_MISMATCH_LINES) return fail(COLBWT_ERR_ARG, "bad layout");
+    if (layout >= COLBWT_LAYOUT_LINE_ROWS && !fat_steps_supported(steps))
         return fail(COLBWT_ERR_ARG, "line rows: own steps must be 4..8");
     *out = nullptr;
     if (!widths_ok(widths))
@@ -558,10 +559,27 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
     int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
-    while (rc == COLBWT_ERR_NOMEM && automatic && layout > COLBWT_LAYOUT_ONE_STEP) {
-        // the table does not fit (HBM, or more than 2^32-2 refined rows): the next smaller layout
-        --layout;
-        rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
+    if (rc == COLBWT_ERR_NOMEM && automatic) {
+        // The table does not fit that way (HBM, or more than 2^32-2 refined rows): the ladder of
+        // smaller layouts -- mismatch lines, line rows at K = 8, 6, 4, three-, two-, one-step rows.
+        // A line-row build says at which refinement level it gave up (after that level's counting
+        // pass, before anything of it was allocated): candidates that have to pass the same level
+        // are not tried at all, so an index far too large for line rows costs one counting pass.
+        struct Candidate { int layout, steps; };
+        static const Candidate ladder[] = {{COLBWT_LAYOUT_MISMATCH_LINES, 8}, {COLBWT_LAYOUT_LINE_ROWS, 8}, {COLBWT_LAYOUT_LINE_ROWS, 6},
+                                           {COLBWT_LAYOUT_LINE_ROWS, 4},      {COLBWT_LAYOUT_THREE_STEP, 0}, {COLBWT_LAYOUT_TWO_STEP, 0},
+                                           {COLBWT_LAYOUT_ONE_STEP, 0}};
+        int hopeless_from = layout >= COLBWT_LAYOUT_LINE_ROWS ? idx->ix.fat_failed_level() : 0;   // steps >= this cannot be built
+        for (const Candidate &c : ladder) {
+            if (c.layout > layout || (c.layout == layout && (c.steps >= steps || steps_given))) continue;   // at or above the start
+            if (c.layout >= COLBWT_LAYOUT_LINE_ROWS && (steps_given || (hopeless_from && c.steps >= hopeless_from))) continue;
+            rc = idx->ix.load((const uint8_t *)bytes, len, device, c.layout, err, c.steps);
+            if (rc != COLBWT_ERR_NOMEM) break;
+            if (c.layout >= COLBWT_LAYOUT_LINE_ROWS) {
+                const int f = idx->ix.fat_failed_level();
+                if (f && (!hopeless_from || f < hopeless_from)) hopeless_from = f;
+            }
+        }
     }
     if (rc != COLBWT_OK) {
         delete idx;
@@ -606,7 +624,7 @@ int colbwt_index_open_memory_devices(const void *bytes, uint64_t len, const colb
     if (rc != COLBWT_OK) return rc;
     colbwt_info info;
     (void)colbwt_index_info(first, &info);
-    const int same = (int)info.layout | (info.layout == COLBWT_LAYOUT_LINE_ROWS ? (int)(info.layout_shape >> 8) << 8 : 0);
+    const int same = (int)info.layout | (info.layout >= COLBWT_LAYOUT_LINE_ROWS ? (int)(info.layout_shape >> 8) << 8 : 0);
     for (int k = 1; k < n_devices; ++k) {
         colbwt_index *rep = nullptr;
         rc = colbwt_index_open_memory_layout(bytes, len, widths, devices[k], same, &rep);
@@ -646,9 +664,7 @@ int colbwt_index_info(const colbwt_index *idx, colbwt_info *out) {
     out->device = (uint32_t)idx->ix.device();
     out->device_bytes = idx->ix.device_bytes();
     out->layout = (uint32_t)idx->ix.layout();
-    out->layout_shape = idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS
-                            ? (idx->ix.table_fat().steps << 8) | kFatSlotSteps
-                            : 0;
+    out->layout_shape = idx->ix.line_rows() ? (idx->ix.table_fat().steps << 8) | kFatSlotSteps : 0;
     out->table_rows = idx->ix.table_rows();
     out->n_devices = 1 + (uint32_t)idx->more.size();
     out->reserved_ = 0;
@@ -693,7 +709,7 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
         API_HIP(hipEventCreate(&e1));
         API_HIP(hipEventRecord(e0, stream));
     }
-    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+    if (idx->ix.line_rows())
         launch_fat_query(idx->ix.table_fat(), d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
         launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
@@ -938,7 +954,7 @@ int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read
     if (rc != COLBWT_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     API_HIP(hipMemsetAsync(d_bases + n_reads * (uint64_t)read_len, 0, 64, stream));
-    if (idx->ix.layout() == COLBWT_LAYOUT_LINE_ROWS)
+    if (idx->ix.line_rows())
         launch_fat_synth_reads(idx->ix.table_fat(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);
     else if (idx->ix.layout() >= 2)   // the one-step tables are gone once the K-step rows exist
         launch_sk_synth_reads(idx->ix.table_k(), n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream);

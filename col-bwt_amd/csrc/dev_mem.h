@@ -14,6 +14,8 @@
 #include <stdlib.h>
 #include <time.h>
 
+#include <algorithm>
+
 namespace colbwt {
 
 struct DevBudget {
@@ -52,6 +54,19 @@ inline hipError_t dev_alloc(void **p, uint64_t bytes) {
         if (b->used > b->peak) b->peak = b->used;
     }
     return hipSuccess;
+}
+
+// Bytes an open on this thread could still allocate: what the device reports free, within what is
+// left of the budget.  The builders ask before a refinement level is materialised, so a layout that
+// cannot fit gives up after a counting pass instead of after tens of GB of allocations.
+inline uint64_t dev_available_bytes() {
+    size_t free_b = 0, total_b = 0;
+    uint64_t avail = ~0ull;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = free_b;
+    else (void)hipGetLastError();
+    const DevBudget *b = current_budget();
+    if (b && b->limit != ~0ull) avail = std::min<uint64_t>(avail, b->limit > b->used ? b->limit - b->used : 0);
+    return avail;
 }
 
 inline void dev_free(void *p, uint64_t bytes) {

@@ -34,20 +34,22 @@ struct PlainLevel {
     const uint16_t *O;      // r : offset of that image inside I (< 65535: exact, no fast-forward left)
     const uint16_t *meta;   // r : char | col id << 8
     const uint64_t *thr;    // r : threshold of the BWT run
+    const uint8_t *org;     // r : 1 where an origin row starts (fat_layout.h, mismatch lines)
     uint64_t n;
     uint32_t r;
 };
 
 struct PlainBuffers {
-    DevPtr idx, I, O, meta, thr;
+    DevPtr idx, I, O, meta, thr, org;
     void release() {
-        for (DevPtr *p : {&idx, &I, &O, &meta, &thr}) p->reset();
+        for (DevPtr *p : {&idx, &I, &O, &meta, &thr, &org}) p->reset();
     }
 };
 
 struct SrcPlain {   // a plain level as the source of the next one (the interface of refine.h)
     PlainLevel T;
     __device__ __forceinline__ uint32_t cuts(uint32_t, uint64_t (&)[kHintSlots]) const { return 0; }   // cut in the first pass
+    __device__ __forceinline__ bool origin_start(uint32_t i, uint64_t b) const { return b == T.idx[i] && T.org[i]; }
     __device__ __forceinline__ uint32_t rows() const { return T.r; }
     __device__ __forceinline__ uint64_t n() const { return T.n; }
     __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
@@ -67,7 +69,7 @@ template <class Src>
 __global__ __launch_bounds__(256) void plain_emit_kernel(Src S, const uint32_t *__restrict__ first,
                                                          uint64_t *__restrict__ idx_new, uint32_t *__restrict__ I_new,
                                                          uint16_t *__restrict__ meta_new, uint64_t *__restrict__ thr_new,
-                                                         uint64_t *__restrict__ park, uint32_t r_new) {
+                                                         uint8_t *__restrict__ org_new, uint64_t *__restrict__ park, uint32_t r_new) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= S.rows()) return;
     const uint32_t meta = S.ch_at((uint32_t)i, 1) | (S.cid_at((uint32_t)i, 1) << 8);
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(256) void plain_emit_kernel(Src S, const uint32_t *
         park[out] = S.idx(j) + t;
         meta_new[out] = (uint16_t)meta;
         thr_new[out] = thr;
+        org_new[out] = S.origin_start((uint32_t)i, b) ? 1 : 0;
         ++out;
     });
     if (i + 1 == S.rows()) idx_new[r_new] = S.n();   // sentinel
@@ -151,15 +154,86 @@ __device__ __forceinline__ void plain_lf(const PlainLevel &P, uint32_t &j, uint6
 __device__ __forceinline__ void put_byte(uint32_t *w, uint32_t off, uint32_t v) { w[off >> 2] |= (v & 0xFFu) << (8 * (off & 3u)); }
 __device__ __forceinline__ void put_half(uint32_t *w, uint32_t off, uint32_t v) { w[off >> 2] |= (v & 0xFFFFu) << (8 * (off & 2u)); }
 
-template <int K>
-__global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T, uint8_t *__restrict__ lines) {
+// col_pml::threshold_step (col_bwt.hpp:531-574) resolved for a whole row: where a mismatch on the
+// character with dense index cidx takes EVERY position of level-K row i -- the head of the
+// succeeding run of that character or the tail of the preceding one, decided by the row's place
+// relative to the threshold.  false: there is no such run, or the threshold lies inside the row
+// (the query decides at run time).
+__device__ __forceinline__ bool fat_slot_target(const PlainLevel &P, const FatTable &T, uint32_t i, uint32_t cidx, uint32_t &tj,
+                                                uint64_t &to) {
+    const uint64_t lo = P.idx[i], len = P.idx[(uint64_t)i + 1] - lo;
+    const uint32_t c = (T.top4 >> (8 * cidx)) & 0xFFu;
+    const uint32_t s = fat_succ_char(T, i, c, cidx);                 // :548
+    const uint64_t thr = s != kNone ? P.thr[s] : P.n;                // :535 / :553
+    tj = kNone;
+    to = 0;
+    if (lo + len - 1 < thr) {                                        // :560 true for the whole row
+        const uint32_t q = fat_pred_char(T, i, c, cidx);             // :562
+        if (q != kNone) { tj = q; to = P.idx[(uint64_t)q + 1] - P.idx[q] - 1; }   // :565-569
+        else if (s != kNone) { tj = s; to = 0; }                     // :552-557
+    } else if (lo >= thr) {                                          // false for the whole row
+        tj = s;                                                      // exists: thr < n
+        to = 0;
+    }                                                                // else: the threshold is inside the row
+    return tj != kNone;
+}
+
+// ---- origin rows (fat_layout.h, mismatch lines): rho[i] = origin row of level-K row i, rho_first
+// its first level-K row.  `rho` arrives holding the exclusive prefix sum of the origin-start flags.
+__global__ __launch_bounds__(256) void org_flags_kernel(const uint8_t *__restrict__ org, uint32_t r, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < r) out[i] = org[i] ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void rho_kernel(const uint8_t *__restrict__ org, uint32_t r, uint32_t *__restrict__ rho,
+                                                  uint32_t *__restrict__ rho_first) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= r) return;
+    const uint32_t flag = org[i] ? 1u : 0u;
+    const uint32_t id = rho[i] + flag - 1u;      // row 0 starts an origin row
+    rho[i] = id;
+    if (flag) rho_first[id] = (uint32_t)i;
+}
+
+// Per level-K row: index of its character among the four most frequent << 4 (7 = other) | bit s =
+// mismatch slot s is decided for the row AND takes it where it takes the first row of its origin
+// row -- the entry of (origin row, slot) is packed from that first row, and every row that points
+// a lane to it must mean the same position.  (Rows are cut at the thresholds of the slotted
+// characters, so the two agree whenever both are decided; the comparison is the guarantee.)
+__global__ __launch_bounds__(256) void fat_slot_flags_kernel(PlainLevel P, FatTable T, const uint32_t *__restrict__ rho,
+                                                             const uint32_t *__restrict__ rho_first, uint8_t *__restrict__ flags) {
+    const uint64_t i64 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i64 >= P.r) return;
+    const uint32_t i = (uint32_t)i64;
+    const uint32_t a_dense = T.cmap[P.meta[i] & 0xFFu];
+    uint32_t f = (a_dense < 4 ? a_dense : kFatOwnOther) << 4;
+    const uint32_t head = rho_first[rho[i]];
+    const uint32_t top = T.sigma < 4 ? T.sigma : 4;
+    for (uint32_t cidx = 0; cidx < top; ++cidx) {
+        if (cidx == a_dense) continue;
+        const uint32_t slot = hint_slot(cidx, a_dense);
+        if (slot >= kFatSlots) continue;
+        uint32_t tj, hj;
+        uint64_t to, ho;
+        if (!fat_slot_target(P, T, i, cidx, tj, to)) continue;
+        if (head != i && (!fat_slot_target(P, T, head, cidx, hj, ho) || hj != tj || ho != to)) continue;
+        f |= 1u << slot;
+    }
+    flags[i] = (uint8_t)f;
+}
+
+// kMis = false: rows with in-row mismatch slots; true: rows of the mismatch-line variant (rho,
+// sflags: the arrays of the two kernels above).
+template <int K, bool kMis>
+__global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T, const uint32_t *__restrict__ rho,
+                                                       const uint8_t *__restrict__ sflags, uint8_t *__restrict__ lines) {
     const uint64_t i64 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i64 >= P.r) return;
     const uint32_t i = (uint32_t)i64;
     uint32_t w[kFatRowBytes / 4];
 #pragma unroll
     for (uint32_t q = 0; q < kFatRowBytes / 4; ++q) w[q] = 0;
-    const uint64_t lo = P.idx[i], len = P.idx[(uint64_t)i + 1] - lo;
+    const uint64_t len = P.idx[(uint64_t)i + 1] - P.idx[i];
     put_half(w, kFatLen, (uint32_t)len);
 
     // ---- the row's own K steps
@@ -172,6 +246,20 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
         if (s == 1) own_ch = meta & 0xFFu;
         put_byte(w, kFatCh + (8 - s), meta & 0xFFu);
         put_byte(w, kFatCid + (8 - s), meta >> 8);
+        if constexpr (kMis) {
+            // The row met after s - 1 steps: its origin row, which of its entries exist.  A level-K
+            // row stays inside ONE row of level K - s + 1 for s - 1 steps, and from level 2 up those
+            // are cut at the thresholds -- but after K - 1 steps all that is left is "one row of the
+            // file", whose threshold cuts the image may straddle: then the positions of this row
+            // are in different origin rows at that depth and no single entry is theirs.
+            bool one_origin = true;
+            if (s == K) {
+                const uint64_t end = P.idx[j] + t + len;     // image = [idx[j] + t, end)
+                for (uint64_t q = (uint64_t)j + 1; q < P.r && P.idx[q] < end; ++q) one_origin = one_origin && !P.org[q];
+            }
+            w[kFatRho / 4 + (s - 1)] = rho[j];
+            if (one_origin) w[kFatVal / 4] |= (uint32_t)(sflags[j] & 7u) << (3 * (s - 1));   // 24 bits of one dword
+        }
         plain_lf(P, j, t);                                   // (j, t) = LF^s(first position)
         w[kFatI / 4 + (s - 1)] = j;
         put_half(w, kFatO + 2 * (s - 1), (uint32_t)t);
@@ -190,45 +278,83 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
         put_byte(w, kFatCut + (s - 1), cut | (len_b << 4));
     }
 
-    // ---- the mismatch slots: col_pml::threshold_step (col_bwt.hpp:531-574) resolved per row
-    const uint32_t a_dense = T.cmap[own_ch];
-    const uint32_t aidx = a_dense < 4 ? a_dense : kFatOwnOther;
-    uint32_t flags = aidx << 4;
-    const uint32_t top = T.sigma < 4 ? T.sigma : 4;
-    for (uint32_t cidx = 0; cidx < top; ++cidx) {
-        if (cidx == a_dense) continue;
-        const uint32_t slot = hint_slot(cidx, a_dense);
-        if (slot >= kFatSlots) continue;
-        const uint32_t c = (T.top4 >> (8 * cidx)) & 0xFFu;
-        const uint32_t s = fat_succ_char(T, i, c, cidx);                 // :548
-        const uint64_t thr = s != kNone ? P.thr[s] : P.n;                // :535 / :553
-        uint32_t tj = kNone;
-        uint64_t to = 0;
-        if (lo + len - 1 < thr) {                                        // :560 true for the whole row
-            const uint32_t q = fat_pred_char(T, i, c, cidx);             // :562
-            if (q != kNone) { tj = q; to = P.idx[(uint64_t)q + 1] - P.idx[q] - 1; }   // :565-569
-            else if (s != kNone) { tj = s; to = 0; }                     // :552-557
-        } else if (lo >= thr) {                                          // false for the whole row
-            tj = s;                                                      // exists: thr < n
-            to = 0;
-        }                                                                // else: the threshold is inside the row
-        if (tj == kNone) continue;                                       // the query decides at run time
-        flags |= 1u << slot;
-        const uint32_t sb = kFatSlot0 + slot * kFatSlotBytes;
-        plain_lf(P, tj, to);                                             // LF(p_c)
-        w[sb >> 2] = tj;
-        put_half(w, sb + kFatSlotP, (uint32_t)to);
-        const uint32_t meta = P.meta[tj];                                // met after one step
-        put_byte(w, sb + kFatSlotCh2, meta & 0xFFu);
-        put_byte(w, sb + kFatSlotCid2, meta >> 8);
-        plain_lf(P, tj, to);                                             // LF^2(p_c)
-        w[(sb >> 2) + 1] = tj;
-        put_half(w, sb + kFatSlotP + 2, (uint32_t)to);
+    if constexpr (kMis) {
+        put_byte(w, kFatFlags, sflags[i]);
+    } else {
+        // ---- the mismatch slots: col_pml::threshold_step (col_bwt.hpp:531-574) resolved per row
+        const uint32_t a_dense = T.cmap[own_ch];
+        const uint32_t aidx = a_dense < 4 ? a_dense : kFatOwnOther;
+        uint32_t flags = aidx << 4;
+        const uint32_t top = T.sigma < 4 ? T.sigma : 4;
+        for (uint32_t cidx = 0; cidx < top; ++cidx) {
+            if (cidx == a_dense) continue;
+            const uint32_t slot = hint_slot(cidx, a_dense);
+            if (slot >= kFatSlots) continue;
+            uint32_t tj;
+            uint64_t to;
+            if (!fat_slot_target(P, T, i, cidx, tj, to)) continue;       // the query decides at run time
+            flags |= 1u << slot;
+            const uint32_t sb = kFatSlot0 + slot * kFatSlotBytes;
+            plain_lf(P, tj, to);                                         // LF(p_c)
+            w[sb >> 2] = tj;
+            put_half(w, sb + kFatSlotP, (uint32_t)to);
+            const uint32_t meta = P.meta[tj];                            // met after one step
+            put_byte(w, sb + kFatSlotCh2, meta & 0xFFu);
+            put_byte(w, sb + kFatSlotCid2, meta >> 8);
+            plain_lf(P, tj, to);                                         // LF^2(p_c)
+            w[(sb >> 2) + 1] = tj;
+            put_half(w, sb + kFatSlotP + 2, (uint32_t)to);
+        }
+        put_byte(w, kFatFlags, flags);
     }
-    put_byte(w, kFatFlags, flags);
     uint4 *dst = reinterpret_cast<uint4 *>(lines + (uint64_t)i * kFatRowBytes);
 #pragma unroll
     for (uint32_t q = 0; q < kFatRowBytes / 16; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
+// One thread per mismatch entry e = 3 * origin row + slot (fat_layout.h): p_c of the origin row,
+// q1 = LF(p_c), and the landing after the NEXT base for each thing that base can do.
+__global__ __launch_bounds__(256) void fat_mis_pack_kernel(PlainLevel P, FatTable T, const uint32_t *__restrict__ rho,
+                                                           const uint32_t *__restrict__ rho_first,
+                                                           const uint8_t *__restrict__ sflags, uint8_t *__restrict__ entries) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (uint64_t)T.n_rho * kFatSlots) return;
+    uint32_t w[kMisBytes / 4];
+#pragma unroll
+    for (uint32_t q = 0; q < kMisBytes / 4; ++q) w[q] = 0;
+    const uint32_t i = rho_first[e / kFatSlots], slot = (uint32_t)(e % kFatSlots);
+    if ((sflags[i] >> slot) & 1u) {
+        const uint32_t a_dense = T.cmap[P.meta[i] & 0xFFu];
+        uint32_t tj;
+        uint64_t to;
+        fat_slot_target(P, T, i, slot < a_dense ? slot : slot + 1, tj, to);      // exists: the flag says so
+        plain_lf(P, tj, to);                                                      // q1 = LF(p_c)
+        const uint32_t J1 = tj;
+        const uint64_t P1 = to;
+        const uint32_t m1 = P.meta[J1], a1 = T.cmap[m1 & 0xFFu], v1 = sflags[J1] & 7u;
+        w[kMisJ1] = J1;
+        w[kMisP1] = (uint32_t)P1 | ((m1 & 0xFFu) << 16) | ((m1 >> 8) << 24);
+        w[kMisVal] = v1;
+        for (uint32_t o = 0; o < 4; ++o) {
+            uint32_t j = J1;
+            uint64_t t = P1;
+            if (o) {                                                              // a mismatch on slot o - 1 of q1's origin row
+                if (!((v1 >> (o - 1)) & 1u)) continue;
+                fat_slot_target(P, T, J1, (o - 1) < a1 ? o - 1 : o, j, t);
+            }
+            plain_lf(P, j, t);
+            const uint32_t m = P.meta[j];
+            w[kMisJ + o] = j;
+            w[kMisRho + o] = rho[j];
+            put_half(w, 4 * kMisP + 2 * o, (uint32_t)t);
+            put_byte(w, 4 * kMisCh + o, m & 0xFFu);
+            put_byte(w, 4 * kMisCid + o, m >> 8);
+            w[kMisVal] |= (uint32_t)(sflags[j] & 7u) << (4 + 4 * o);
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(entries + e * kMisBytes);
+#pragma unroll
+    for (uint32_t q = 0; q < kMisBytes / 16; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 // One refinement pass into the plain form.  COLBWT_OK / COLBWT_ERR_NOMEM (HBM, row limit) /
@@ -245,19 +371,28 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
         err = "line-row layout needs " + std::to_string(total) + " rows at one of its levels (> 2^32-2)";
         return COLBWT_ERR_NOMEM;
     }
+    // The final level has at least as many rows as this one, each a 128-byte line: when that alone
+    // is beyond what can still be allocated the build cannot succeed -- say so after the counting
+    // pass, before tens of GB are allocated and filled only to be given back.
+    if (total * kFatRowBytes > dev_available_bytes()) {
+        err = "line-row layout: " + std::to_string(total) + " rows at a refinement level need more HBM than is available";
+        return COLBWT_ERR_NOMEM;
+    }
     const uint32_t r_new = (uint32_t)total;
     SK_TRY(buf.idx.alloc(((uint64_t)r_new + 2) * sizeof(uint64_t)));
     SK_TRY(buf.I.alloc(((uint64_t)r_new + 1) * sizeof(uint32_t)));
     SK_TRY(buf.O.alloc(((uint64_t)r_new + 1) * sizeof(uint16_t)));
     SK_TRY(buf.meta.alloc(((uint64_t)r_new + 1) * sizeof(uint16_t)));
     SK_TRY(buf.thr.alloc(((uint64_t)r_new + 1) * sizeof(uint64_t)));
+    SK_TRY(buf.org.alloc((uint64_t)r_new + 1));
     SK_TRY(park.alloc(((uint64_t)r_new + 1) * sizeof(uint64_t)));
     uint64_t *const d_idx = buf.idx.as<uint64_t>(), *const d_thr = buf.thr.as<uint64_t>(), *const d_park = park.as<uint64_t>();
     uint32_t *const d_I = buf.I.as<uint32_t>(), *const d_first = first.as<uint32_t>();
     uint16_t *const d_O = buf.O.as<uint16_t>(), *const d_meta = buf.meta.as<uint16_t>();
+    uint8_t *const d_org = buf.org.as<uint8_t>();
     const uint32_t rblocks = (uint32_t)((src_rows + 255) / 256);
     hipLaunchKernelGGL(plain_emit_kernel<Src>, dim3(rblocks), dim3(256), 0, 0, S, (const uint32_t *)d_first, d_idx, d_I, d_meta,
-                       d_thr, d_park, r_new);
+                       d_thr, d_org, d_park, r_new);
     SK_TRY(hipGetLastError());
     SK_TRY(hipStreamSynchronize(0));
     const uint32_t nblocks = (uint32_t)(((uint64_t)r_new + 255) / 256);
@@ -270,14 +405,16 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
     out.O = d_O;
     out.meta = d_meta;
     out.thr = d_thr;
+    out.org = d_org;
     out.n = n;
     out.r = r_new;
     return COLBWT_OK;
 }
 
 template <int K>
-int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, FatBuffers &buf, std::string &err,
-                    const std::function<void()> &source_done) {
+int build_fat_steps(const DevTable &T1, const HintChars &chars, bool mismatch_lines, FatTable &out, FatBuffers &buf, std::string &err,
+                    const std::function<void()> &source_done, int &failed_level) {
+    failed_level = 2;
     const uint8_t *cmap = T1.cmap;
     const uint32_t sigma = T1.sigma;
     PlainLevel cur{};
@@ -292,6 +429,7 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
     source_done();
     clock.lap("  one-step tables freed");
     for (int level = 3; level <= K; ++level) {
+        failed_level = level;
         PlainLevel next{};
         PlainBuffers next_buf;
         const SrcPlain sp{cur};
@@ -304,9 +442,11 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
         cur_buf.O = std::move(next_buf.O);
         cur_buf.meta = std::move(next_buf.meta);
         cur_buf.thr = std::move(next_buf.thr);
+        cur_buf.org = std::move(next_buf.org);
         clock.lap("  refinement level (3..K)");
     }
 
+    failed_level = K + 1;                 // from here on it is the size of the final tables that may not fit
     const uint32_t r = cur.r;
     out = FatTable{};
     out.n = cur.n;
@@ -346,11 +486,58 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, FatTable &out, F
     out.thr = cur.thr;
 
     clock.lap("  characters, jump tables");
-    SK_TRY(buf.lines.alloc(((uint64_t)r + 1) * kFatRowBytes));
+    // ---- origin rows and which of their mismatch entries exist (mismatch-line variant)
+    DevPtr rho_buf, rho_first_buf, sflags_buf;
+    uint64_t mis_lines = 0;
+    uint32_t *d_rho = nullptr, *d_rho_first = nullptr;     // raw pointers for the launches
+    uint8_t *d_sflags = nullptr;
+    if (mismatch_lines) {
+        SK_TRY(rho_buf.alloc(((uint64_t)r + 1) * sizeof(uint32_t)));
+        d_rho = rho_buf.as<uint32_t>();
+        const uint8_t *const d_org = cur.org;
+        hipLaunchKernelGGL(org_flags_kernel, dim3(nblocks), dim3(256), 0, 0, d_org, r, d_rho);
+        SK_TRY(hipGetLastError());
+        uint64_t n_rho = 0;
+        {
+            const int rc = exclusive_scan_u32(d_rho, r, n_rho, err);
+            if (rc != COLBWT_OK) return rc;
+        }
+        mis_lines = (n_rho * kFatSlots * kMisBytes + kFatRowBytes - 1) / kFatRowBytes;
+        if ((uint64_t)r + 1 + mis_lines > 0xFFFFFFFEull) {
+            err = "line rows + mismatch lines need " + std::to_string((uint64_t)r + 1 + mis_lines) + " lines (> 2^32-2)";
+            return COLBWT_ERR_NOMEM;
+        }
+        out.n_rho = (uint32_t)n_rho;
+        out.slot_line0 = r + 1;
+        SK_TRY(rho_first_buf.alloc((n_rho + 1) * sizeof(uint32_t)));
+        SK_TRY(sflags_buf.alloc((uint64_t)r + 1));
+        d_rho_first = rho_first_buf.as<uint32_t>();
+        d_sflags = sflags_buf.as<uint8_t>();
+        hipLaunchKernelGGL(rho_kernel, dim3(nblocks), dim3(256), 0, 0, d_org, r, d_rho, d_rho_first);
+        SK_TRY(hipGetLastError());
+        hipLaunchKernelGGL(fat_slot_flags_kernel, dim3(nblocks), dim3(256), 0, 0, cur, out, (const uint32_t *)d_rho,
+                           (const uint32_t *)d_rho_first, d_sflags);
+        SK_TRY(hipGetLastError());
+        SK_TRY(hipStreamSynchronize(0));
+        clock.lap("  origin rows, entry flags");
+    }
+    SK_TRY(buf.lines.alloc(((uint64_t)r + 1 + mis_lines) * kFatRowBytes));
     clock.lap("  lines allocated");
     uint8_t *const d_lines = buf.lines.as<uint8_t>();
     SK_TRY(hipMemset(d_lines + (uint64_t)r * kFatRowBytes, 0, kFatRowBytes));
-    hipLaunchKernelGGL(fat_pack_kernel<K>, dim3(nblocks), dim3(256), 0, 0, cur, out, d_lines);
+    if (mismatch_lines) {
+        hipLaunchKernelGGL((fat_pack_kernel<K, true>), dim3(nblocks), dim3(256), 0, 0, cur, out, (const uint32_t *)d_rho,
+                           (const uint8_t *)d_sflags, d_lines);
+        SK_TRY(hipGetLastError());
+        uint8_t *const d_entries = d_lines + ((uint64_t)r + 1) * kFatRowBytes;
+        if (mis_lines) SK_TRY(hipMemset(d_entries + (mis_lines - 1) * kFatRowBytes, 0, kFatRowBytes));   // the odd half of the last line
+        const uint64_t n_entries = (uint64_t)out.n_rho * kFatSlots;
+        hipLaunchKernelGGL(fat_mis_pack_kernel, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, 0, cur, out,
+                           (const uint32_t *)d_rho, (const uint32_t *)d_rho_first, (const uint8_t *)d_sflags, d_entries);
+    } else {
+        hipLaunchKernelGGL((fat_pack_kernel<K, false>), dim3(nblocks), dim3(256), 0, 0, cur, out, (const uint32_t *)nullptr,
+                           (const uint8_t *)nullptr, d_lines);
+    }
     SK_TRY(hipGetLastError());
     SK_TRY(hipStreamSynchronize(0));
     out.lines = d_lines;
@@ -414,14 +601,16 @@ bool fat_steps_supported(int steps) {
 
 // Builds the line-row layout with `steps` own steps from the one-step tables.  Same contract as
 // build_sk.
-int build_fat(const DevTable &T, const HintChars &chars, int steps, FatTable &out, FatBuffers &buf, std::string &err,
-              const std::function<void()> &source_done) {
-    int rc = COLBWT_ERR_ARG;
+int build_fat(const DevTable &T, const HintChars &chars, int steps, bool mismatch_lines, FatTable &out, FatBuffers &buf,
+              std::string &err, const std::function<void()> &source_done, int *failed_level) {
+    int rc = COLBWT_ERR_ARG, level = 0;
     err = "unsupported number of line-row steps";
-#define X(K) if (steps == K) rc = build_fat_steps<K>(T, chars, out, buf, err, source_done);
+#define X(K) if (steps == K) rc = build_fat_steps<K>(T, chars, mismatch_lines, out, buf, err, source_done, level);
+    if (failed_level) *failed_level = 0;
     COLBWT_FAT_STEPS(X)
 #undef X
     if (rc != COLBWT_OK) buf.release();
+    if (rc != COLBWT_OK && failed_level) *failed_level = level;
     return rc;
 }
 

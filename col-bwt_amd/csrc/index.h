@@ -28,14 +28,15 @@ public:
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
     // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1);
-    // 4 = line rows (fat_layout.h) with `steps` own steps.
+    // 4 = line rows (fat_layout.h) with `steps` own steps; 5 = the same with mismatch lines.
     int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err, int steps = 0);
 
     const DevTable &table() const { return tbl_; }
     const SKTable &table_k() const { return tblk_; }
     const FatTable &table_fat() const { return tblf_; }
     int layout() const { return layout_; }
-    uint64_t table_rows() const { return layout_ == 4 ? tblf_.r : (layout_ >= 2 ? tblk_.r : tbl_.r); }
+    bool line_rows() const { return layout_ == 4 || layout_ == 5; }
+    uint64_t table_rows() const { return line_rows() ? tblf_.r : (layout_ >= 2 ? tblk_.r : tbl_.r); }
     int device() const { return device_; }
     uint64_t bwt_r() const { return bwt_r_; }
     uint64_t n() const { return tbl_.n; }
@@ -43,6 +44,8 @@ public:
     uint32_t sigma() const { return tbl_.sigma; }
     uint64_t device_bytes() const;                                  // HBM held now
     uint64_t peak_device_bytes() const { return peak_device_bytes_; }  // ... and at most while loading
+    // after a failed line-row load: the refinement level that did not fit (query_kernels.h build_fat), else 0
+    int fat_failed_level() const { return fat_failed_level_; }
 
 private:
     void release();
@@ -53,6 +56,7 @@ private:
     FatTable tblf_{};
     FatBuffers buff_;
     int layout_ = 1;
+    int fat_failed_level_ = 0;
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t peak_device_bytes_ = 0;

@@ -75,14 +75,21 @@ struct FatBuffers {
     uint64_t bytes() const;
     void release();
 };
-// Line rows with `steps` own steps (fat_build.hip); same contract as build_sk.
-// fat_steps_supported: the step counts compiled in.
+// Line rows with `steps` own steps (fat_build.hip), with in-row mismatch slots or with mismatch
+// lines (fat_layout.h); same contract as build_sk.
+// fat_steps_supported: the step counts compiled in.  On failure *failed_level (nullable) says how
+// far the build got: the refinement level (2 .. steps) that could not be built -- a build with
+// at least that many steps fails the same way -- or steps + 1 when the levels fit and the final
+// tables did not.
 bool fat_steps_supported(int steps);
-int build_fat(const DevTable &T, const HintChars &chars, int steps, FatTable &out, FatBuffers &buf, std::string &err,
-              const std::function<void()> &source_done);
+int build_fat(const DevTable &T, const HintChars &chars, int steps, bool mismatch_lines, FatTable &out, FatBuffers &buf,
+              std::string &err, const std::function<void()> &source_done, int *failed_level);
 // The query over line rows (fat_query.hip).
 void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                       void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
+// ... over line rows with mismatch lines (fat2_query.hip; launch_fat_query dispatches to it)
+void launch_fat2_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
+                       void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream);
 void launch_fat_synth_reads(const FatTable &T, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                             uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, hipStream_t stream);
 

@@ -54,6 +54,17 @@ struct SrcL1 {  // the one-step table
         }
         return nc;
     }
+    // Does an ORIGIN row start at position b of row i?  Origin rows are the rows of the file cut at
+    // the thresholds inside them (the cuts above): where threshold_step goes is one position per
+    // origin row and character (fat_layout.h, mismatch lines).
+    __device__ __forceinline__ bool origin_start(uint32_t i, uint64_t b) const {
+        if (b == T.idx[i]) return true;
+        uint64_t cut[kHintSlots];
+        const uint32_t nc = cuts(i, cut);
+        for (uint32_t q = 0; q < nc; ++q)
+            if (cut[q] == b) return true;
+        return false;
+    }
     __device__ __forceinline__ uint32_t rows() const { return T.r; }
     __device__ __forceinline__ uint64_t n() const { return T.n; }
     __device__ __forceinline__ uint64_t idx(uint32_t j) const { return T.idx[j]; }
@@ -185,23 +196,14 @@ __device__ __forceinline__ uint32_t sk_find(const uint64_t *idx_new, const uint3
         }                                                                              \
     } while (0)
 
-// count + scan of one refinement pass: `first` receives (rows + 1) u32, first[i] = first new row
-// of source row i and first[rows] = `total`, which may exceed 32 bits (then first[] is
-// meaningless and the caller gives up).
-template <class Src>
-int count_and_scan(const Src &S, uint64_t rows, DevPtr &first, uint64_t &total, std::string &err) {
+// Exclusive prefix sum of d_data[0 .. n) in place (u32 items; the sum may exceed 32 bits, then the
+// items are meaningless and `total` says so).
+inline int exclusive_scan_u32(uint32_t *d_data, uint64_t n, uint64_t &total, std::string &err) {
     DevPtr tot_buf;
-    SK_TRY(first.alloc((rows + 1) * sizeof(uint32_t)));
-    uint32_t *d_first = first.as<uint32_t>();
-    const uint32_t rblocks = (uint32_t)((rows + 255) / 256);
-    hipLaunchKernelGGL(sk_count_kernel<Src>, dim3(rblocks), dim3(256), 0, 0, S, d_first);
-    SK_TRY(hipGetLastError());
-    SK_TRY(hipMemset(d_first + rows, 0, sizeof(uint32_t)));   // the extra slot receives the total
-    const uint64_t nscan = rows + 1;
-    const uint32_t sblocks = (uint32_t)((nscan + 1023) / 1024);
-    SK_TRY(tot_buf.alloc(sblocks * sizeof(uint32_t)));
+    const uint32_t sblocks = (uint32_t)((n + 1023) / 1024);
+    SK_TRY(tot_buf.alloc((sblocks ? sblocks : 1) * sizeof(uint32_t)));
     uint32_t *d_tot = tot_buf.as<uint32_t>();
-    hipLaunchKernelGGL(scan_block_kernel, dim3(sblocks), dim3(256), 0, 0, d_first, nscan, d_tot);
+    hipLaunchKernelGGL(scan_block_kernel, dim3(sblocks), dim3(256), 0, 0, d_data, n, d_tot);
     SK_TRY(hipStreamSynchronize(0));
     std::vector<uint32_t> tot(sblocks);
     SK_TRY(hipMemcpy(tot.data(), d_tot, sblocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -214,9 +216,23 @@ int count_and_scan(const Src &S, uint64_t rows, DevPtr &first, uint64_t &total, 
     total = run;
     if (run > 0xFFFFFFFEull) return COLBWT_OK;
     SK_TRY(hipMemcpy(d_tot, tot.data(), sblocks * sizeof(uint32_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(scan_add_kernel, dim3(sblocks), dim3(256), 0, 0, d_first, nscan, d_tot);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(sblocks), dim3(256), 0, 0, d_data, n, d_tot);
     SK_TRY(hipStreamSynchronize(0));
     return COLBWT_OK;
+}
+
+// count + scan of one refinement pass: `first` receives (rows + 1) u32, first[i] = first new row
+// of source row i and first[rows] = `total`, which may exceed 32 bits (then first[] is
+// meaningless and the caller gives up).
+template <class Src>
+int count_and_scan(const Src &S, uint64_t rows, DevPtr &first, uint64_t &total, std::string &err) {
+    SK_TRY(first.alloc((rows + 1) * sizeof(uint32_t)));
+    uint32_t *d_first = first.as<uint32_t>();
+    const uint32_t rblocks = (uint32_t)((rows + 255) / 256);
+    hipLaunchKernelGGL(sk_count_kernel<Src>, dim3(rblocks), dim3(256), 0, 0, S, d_first);
+    SK_TRY(hipGetLastError());
+    SK_TRY(hipMemset(d_first + rows, 0, sizeof(uint32_t)));   // the extra slot receives the total
+    return exclusive_scan_u32(d_first, rows + 1, total, err);
 }
 
 }  // namespace

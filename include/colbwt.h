@@ -59,7 +59,7 @@ typedef struct colbwt_info {
     uint32_t sigma;        /* distinct characters present in the table */
     uint32_t device;       /* HIP device ordinal                       */
     uint64_t device_bytes; /* HBM held by the index                    */
-    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS */
+    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS / _MISMATCH_LINES */
     uint32_t layout_shape; /* line rows: own steps << 8 | steps per mismatch slot; else 0 */
     uint64_t table_rows;   /* rows of the HBM table actually queried   */
     uint32_t n_devices;    /* replicas of the table (colbwt_index_open_devices); the fields above describe the first */
@@ -108,6 +108,13 @@ int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colb
  * (number of look-ahead steps K, 4..8) may be given; 0 = the engine's default. */
 #define COLBWT_LAYOUT_LINE_ROWS 4
 #define COLBWT_LAYOUT_LINE_ROWS_STEPS(K) (COLBWT_LAYOUT_LINE_ROWS | ((K) << 8))
+/* MISMATCH_LINES: line rows whose mismatch information lives in a table of its own, one 64-byte
+ * entry per (row of the file cut at its thresholds, character): an entry resolves the mismatching
+ * base and the base after it whatever that base is, and a stretch of mismatching bases goes from
+ * entry to entry -- a line fill per two bases instead of one per base.  LINE_ROWS + ~190 bytes per
+ * row of the file. */
+#define COLBWT_LAYOUT_MISMATCH_LINES 5
+#define COLBWT_LAYOUT_MISMATCH_LINES_STEPS(K) (COLBWT_LAYOUT_MISMATCH_LINES | ((K) << 8))
 int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
                              colbwt_index **out);
 int colbwt_index_open_memory_layout(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,

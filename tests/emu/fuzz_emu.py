@@ -41,7 +41,9 @@ def one(seed):
     reads += helpers.backward_walk_reads(img, 25, int(rng.integers(1, 90)), 0.03, seed=seed)
     bases, off = helpers.concat_reads(reads)
     ep, ec = oracle.OracleIndex(img).query_batch(bases, off)
-    for layout in (1, 2, 3) + ((4,) if seed % 3 == 0 else ((4 | (6 << 8),) if seed % 3 == 1 else ())):
+    # line rows (4) and line rows with mismatch lines (5), at varying depths
+    fat = {0: (4, 5 | (4 << 8)), 1: (4 | (6 << 8), 5), 2: (5 | ((4 + seed // 3 % 5) << 8),)}[seed % 3]
+    for layout in (1, 2, 3) + fat:
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         p, c, _ = tbl.query_batch(bases, off)
         assert np.array_equal(p, ep) and np.array_equal(c, ec), f"seed {seed} layout {layout} sigma {sigma} r {r}"

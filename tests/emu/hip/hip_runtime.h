@@ -161,6 +161,7 @@ static inline hipError_t hipMalloc(void **p, size_t n) {
 }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = *total_b = (size_t)1 << 40; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 enum { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1 };

@@ -31,9 +31,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 LINE_ROWS = 4                     # include/colbwt.h COLBWT_LAYOUT_LINE_ROWS (| steps << 8)
+MIS_LINES = 5                     # COLBWT_LAYOUT_MISMATCH_LINES (| steps << 8)
 
 
-def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS,)):
+def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS, MIS_LINES)):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
@@ -178,7 +179,7 @@ def main():
         reads = helpers.backward_walk_reads(img, 40, 70, 0.02, seed=seed)
         reads += rand_reads(rng, 40, 0, 90)
         reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
-        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS,), 257: (LINE_ROWS | (5 << 8),)}.get(rows, ()))
+        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS, MIS_LINES | (6 << 8)), 257: (LINE_ROWS | (5 << 8), MIS_LINES | (4 << 8))}.get(rows, ()))
     img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=8, thr_mode=1)   # thresholds inside rows: cut out
     check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs")
 
@@ -200,7 +201,7 @@ def main():
     for label, alpha in (("hints_sigma4", b"ACGT"), ("hints_sigma5", b"\x01ACGT"), ("nohints_sigma7", b"\x01ACGNTac")):
         img = helpers.random_table(rng, 1500, alphabet=alpha)
         check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label,
-              extra_layouts=(LINE_ROWS,) if label == "nohints_sigma7" else ())
+              extra_layouts=(LINE_ROWS, MIS_LINES) if label == "nohints_sigma7" else (MIS_LINES | (5 << 8),))
 
     # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
     r = 600

@@ -93,6 +93,7 @@ def main():
                           "Gbase_s": round(nb / np.mean(times) / 1e6, 3),
                           "checksum_ok": (sums[name] == ref) if len(variants) > 1 else None,
                           "checksum_against": variants[0][0] if len(variants) > 1 and k else None,
+                          "checksum": list(sums[name]),   # sums of all PML values / col ids: comparable across processes
                           "rows": a.rows, "reads": n_reads, "read_len": m, "pml_bytes": a.pml_bytes}), flush=True)
 
 
