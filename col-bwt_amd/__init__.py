@@ -26,6 +26,7 @@ EXPORTS = (
     "colbwt_index_close", "colbwt_index_info", "colbwt_query_batch", "colbwt_query_batch_u32",
     "colbwt_query_device", "colbwt_query_device_ordered", "colbwt_query_file", "colbwt_query_file_binary",
     "colbwt_binary_to_text", "colbwt_synth_index_bytes", "colbwt_synth_index", "colbwt_synth_index_thr", "colbwt_pml_pack_device", "colbwt_read_end_mask_device", "colbwt_pml_unpack_device",
+    "colbwt_index_cid_dictionary", "colbwt_cid_code_bits", "colbwt_cid_pack_device", "colbwt_cid_unpack_device",
     "colbwt_synth_reads_device", "colbwt_build_col_pml", "colbwt_build_col_pml_arrays",
     "colbwt_col_split", "colbwt_col_split_arrays", "colbwt_col_split_error",
     "colbwt_rlbwt_build_text", "colbwt_rlbwt_build_files", "colbwt_rlbwt_get", "colbwt_rlbwt_free", "colbwt_rlbwt_error",
@@ -99,6 +100,11 @@ def lib():
     L.colbwt_pml_pack_device.argtypes = [vp, u64, vp, vp]
     L.colbwt_read_end_mask_device.argtypes = [vp, u64, vp, vp]
     L.colbwt_pml_unpack_device.argtypes = [vp, vp, u64, u64, u64, vp, vp]
+    L.colbwt_index_cid_dictionary.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.colbwt_cid_code_bits.argtypes = [C.c_uint32]
+    L.colbwt_cid_code_bits.restype = C.c_uint32
+    L.colbwt_cid_pack_device.argtypes = [vp, u64, vp, C.c_uint32, vp, vp]
+    L.colbwt_cid_unpack_device.argtypes = [vp, u64, u64, vp, C.c_uint32, vp, vp]
     L.colbwt_synth_reads_device.argtypes = [vp, u64, C.c_uint32, C.c_uint32, u64, vp, vp, vp]
     L.colbwt_build_col_pml.argtypes = [C.c_char_p, C.c_char_p]
     L.colbwt_build_col_pml_arrays.argtypes = [vp, u64, vp, vp, u64, vp, u64, vp, u64, vp, u64, C.POINTER(u64)]
@@ -208,6 +214,13 @@ class ColPml:
                                               batch_bases, C.byref(st)))
         return st
 
+    def cid_dictionary(self):
+        """The distinct col ids the table's rows hold, ascending (uint8 array): the dictionary of the gather codec."""
+        ids = np.zeros(256, np.uint8)
+        n = C.c_uint32(0)
+        _check(lib().colbwt_index_cid_dictionary(self._h, ids.ctypes.data, C.byref(n)))
+        return ids[:n.value].copy()
+
     def synth_reads_device(self, n_reads, read_len, sub_permille, seed, d_bases, d_read_off, stream=0):
         _check(lib().colbwt_synth_reads_device(self._h, n_reads, read_len, sub_permille, seed,
                                                d_bases, d_read_off, stream))
@@ -252,6 +265,23 @@ def pml_pack_device(d_pml, n_bases, d_mask, stream=0):
 def read_end_mask_device(d_read_off, n_reads, d_mask, stream=0):
     """Bit set at the last base of every non-empty read (d_mask zeroed by the caller)."""
     _check(lib().colbwt_read_end_mask_device(d_read_off, n_reads, d_mask, stream))
+
+
+def cid_code_bits(n_ids):
+    """Bits per base of the col-id codes of a dictionary of n_ids ids."""
+    return int(lib().colbwt_cid_code_bits(int(n_ids)))
+
+
+def cid_pack_device(d_cid, n_bases, ids, d_planes, stream=0):
+    """Gather codec: col ids -> codes of the dictionary `ids` (uint8 array), cid_code_bits(len(ids)) bit planes per 32 bases."""
+    ids = np.ascontiguousarray(ids, np.uint8)
+    _check(lib().colbwt_cid_pack_device(d_cid, n_bases, ids.ctypes.data, ids.size, d_planes, stream))
+
+
+def cid_unpack_device(d_planes, first_word, n_words, ids, d_cid, stream=0):
+    """Rebuilds the col ids of 32-base words [first_word, first_word + n_words) from their bit planes."""
+    ids = np.ascontiguousarray(ids, np.uint8)
+    _check(lib().colbwt_cid_unpack_device(d_planes, first_word, n_words, ids.ctypes.data, ids.size, d_cid, stream))
 
 
 def pml_unpack_device(d_zero_mask, d_end_mask, first_word, n_words, total_words, d_pml, stream=0):

@@ -946,6 +946,51 @@ int colbwt_pml_unpack_device(const uint32_t *d_zero_mask, const uint32_t *d_end_
     return COLBWT_OK;
 }
 
+int colbwt_index_cid_dictionary(const colbwt_index *idx, uint8_t *ids, uint32_t *n_ids) {
+    if (!idx || !ids || !n_ids) return fail(COLBWT_ERR_ARG, "null argument");
+    uint32_t n = 0;
+    for (uint32_t c = 0; c < 256; ++c)
+        if ((idx->ix.cid_set()[c >> 5] >> (c & 31)) & 1u) ids[n++] = (uint8_t)c;
+    *n_ids = n;
+    return COLBWT_OK;
+}
+
+static uint32_t cid_code_bits(uint32_t n_ids) {
+    uint32_t bits = 1;
+    while ((1u << bits) < n_ids) ++bits;
+    return bits;
+}
+
+uint32_t colbwt_cid_code_bits(uint32_t n_ids) { return n_ids >= 1 && n_ids <= 256 ? cid_code_bits(n_ids) : 0; }
+
+int colbwt_cid_pack_device(const uint8_t *d_cid, uint64_t n_bases, const uint8_t *ids, uint32_t n_ids, uint32_t *d_planes,
+                           void *hip_stream) {
+    if (!d_cid || !ids || !d_planes) return fail(COLBWT_ERR_ARG, "null argument");
+    if (n_ids < 1 || n_ids > 256) return fail(COLBWT_ERR_ARG, "a dictionary holds 1 .. 256 col ids");
+    if ((uintptr_t)d_cid % 16) return fail(COLBWT_ERR_ARG, "d_cid must be 16-byte aligned");
+    CidLut code_of;
+    memset(code_of.v, 0, sizeof(code_of.v));
+    for (uint32_t k = 0; k < n_ids; ++k) code_of.v[ids[k]] = (uint8_t)k;
+    launch_cid_pack(d_cid, n_bases, code_of, cid_code_bits(n_ids), d_planes, (hipStream_t)hip_stream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(COLBWT_ERR_HIP, std::string("colbwt_cid_pack_device: ") + hipGetErrorString(e));
+    return COLBWT_OK;
+}
+
+int colbwt_cid_unpack_device(const uint32_t *d_planes, uint64_t first_word, uint64_t n_words, const uint8_t *ids, uint32_t n_ids,
+                             uint8_t *d_cid, void *hip_stream) {
+    if (!d_planes || !ids || !d_cid) return fail(COLBWT_ERR_ARG, "null argument");
+    if (n_ids < 1 || n_ids > 256) return fail(COLBWT_ERR_ARG, "a dictionary holds 1 .. 256 col ids");
+    if ((uintptr_t)d_cid % 32) return fail(COLBWT_ERR_ARG, "d_cid must be 32-byte aligned");
+    CidLut id_of;
+    memset(id_of.v, 0, sizeof(id_of.v));
+    for (uint32_t k = 0; k < n_ids; ++k) id_of.v[k] = ids[k];
+    launch_cid_unpack(d_planes, first_word, n_words, id_of, cid_code_bits(n_ids), d_cid, (hipStream_t)hip_stream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(COLBWT_ERR_HIP, std::string("colbwt_cid_unpack_device: ") + hipGetErrorString(e));
+    return COLBWT_OK;
+}
+
 int colbwt_synth_reads_device(colbwt_index *idx, uint64_t n_reads, uint32_t read_len, uint32_t sub_permille,
                               uint64_t seed, uint8_t *d_bases, uint64_t *d_read_off, void *hip_stream) {
     if (!idx || !d_bases || !d_read_off || read_len == 0) return fail(COLBWT_ERR_ARG, "bad argument");

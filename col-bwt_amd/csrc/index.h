@@ -42,6 +42,7 @@ public:
     uint64_t n() const { return tbl_.n; }
     uint64_t r() const { return tbl_.r; }
     uint32_t sigma() const { return tbl_.sigma; }
+    const uint32_t *cid_set() const { return cid_set_; }            // 256-bit set of the col ids the table's rows hold
     uint64_t device_bytes() const;                                  // HBM held now
     uint64_t peak_device_bytes() const { return peak_device_bytes_; }  // ... and at most while loading
     // after a failed line-row load: the refinement level that did not fit (query_kernels.h build_fat), else 0
@@ -57,6 +58,7 @@ private:
     FatBuffers buff_;
     int layout_ = 1;
     int fat_failed_level_ = 0;
+    uint32_t cid_set_[8] = {};
     uint64_t bwt_r_ = 0;
     int device_ = -1;
     uint64_t peak_device_bytes_ = 0;

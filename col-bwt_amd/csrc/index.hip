@@ -155,6 +155,7 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
         HIP_TRY(hipMemcpy(&h_report, d_report, sizeof(h_report), hipMemcpyDeviceToHost));
     }
     clock.lap("rows uploaded and re-laid out");
+    for (int q = 0; q < 8; ++q) cid_set_[q] = h_report.cids[q];
     if (h_report.flags) {
         err = "corrupt .col_pml near row " + std::to_string(h_report.first_bad) + ":";
         if (h_report.flags & 1u) err += " idx not strictly increasing;";

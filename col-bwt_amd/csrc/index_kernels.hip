@@ -32,11 +32,11 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
                                                                   uint4 *__restrict__ rows, uint64_t *__restrict__ idx_out,
                                                                   uint64_t *__restrict__ thr, RelayoutReport *report) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kStageBytes];
-    __shared__ uint32_t s_present[8];
+    __shared__ uint32_t s_present[8], s_cids[8];
     __shared__ uint32_t s_count[256];
     __shared__ uint32_t s_flags, s_bad;
     const uint64_t blk_row = (uint64_t)blockIdx.x * kRelayoutBlock;  // relative to row0
-    if (threadIdx.x < 8) s_present[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_present[threadIdx.x] = s_cids[threadIdx.x] = 0;
     for (uint32_t t = threadIdx.x; t < 256; t += kRelayoutBlock) s_count[t] = 0;
     if (threadIdx.x == 0) { s_flags = 0; s_bad = kNone; }
 
@@ -81,10 +81,12 @@ __global__ __launch_bounds__(kRelayoutBlock) void relayout_kernel(const uint8_t 
             idx_out[r] = n;
         }
         atomicOr(&s_present[ch >> 5], 1u << (ch & 31));
+        atomicOr(&s_cids[cid >> 5], 1u << (cid & 31));
         atomicAdd(&s_count[ch], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 8 && s_present[threadIdx.x]) atomicOr(&report->present[threadIdx.x], s_present[threadIdx.x]);
+    if (threadIdx.x < 8 && s_cids[threadIdx.x]) atomicOr(&report->cids[threadIdx.x], s_cids[threadIdx.x]);
     for (uint32_t t = threadIdx.x; t < 256; t += kRelayoutBlock)
         if (s_count[t]) atomicAdd(&report->count[t], s_count[t]);
     if (threadIdx.x == 0 && s_flags) {

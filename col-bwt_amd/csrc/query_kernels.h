@@ -33,6 +33,7 @@ struct RelayoutReport {
     uint32_t flags;      // bit0 idx not strictly increasing, bit1 interval >= r, bit2 idx >= n, bit3 idx[0] != 0
     uint32_t first_bad;  // smallest offending row
     uint32_t present[8]; // 256-bit set of characters seen
+    uint32_t cids[8];    // 256-bit set of col ids seen (the dictionary of the gather codec)
     uint32_t count[256]; // rows per character (orders the dense character indices by frequency)
 };
 
@@ -55,6 +56,11 @@ void launch_pml_pack(const uint16_t *d_pml, uint64_t n_bases, uint32_t *d_mask, 
 void launch_read_end_mask(const uint64_t *d_read_off, uint64_t n_reads, uint32_t *d_mask, hipStream_t stream);
 void launch_pml_unpack(const uint32_t *d_flag, const uint32_t *d_last, uint64_t first_word, uint64_t n_words,
                        uint64_t total_words, uint16_t *d_pml, hipStream_t stream);
+// ... and `bits` bits per base for the col ids: codes of a dictionary (the col ids the table holds), as bit planes
+struct CidLut { uint8_t v[256]; };       // pack: col id -> code; unpack: code -> col id
+void launch_cid_pack(const uint8_t *d_cid, uint64_t n_bases, const CidLut &code_of, uint32_t bits, uint32_t *d_planes, hipStream_t stream);
+void launch_cid_unpack(const uint32_t *d_planes, uint64_t first_word, uint64_t n_words, const CidLut &id_of, uint32_t bits,
+                       uint8_t *d_cid, hipStream_t stream);
 
 // Device allocations of one K-step table.
 struct SKBuffers {

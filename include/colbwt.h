@@ -292,7 +292,8 @@ const char *colbwt_rlbwt_error(void);
  * (pml_query.cpp:74).  With the reads sharded over N GPUs the per-base results
  * are gathered on rank 0; the PML values of a read are determined by where
  * they are zero (length + 1 per match, 0 at a mismatch: col_bwt.hpp:516-521),
- * so a rank sends one bit per base and rank 0 rebuilds the 16-bit values.
+ * so a rank sends one bit per base and rank 0 rebuilds the 16-bit values
+ * (the col ids: see colbwt_cid_pack_device below).
  * Device pointers; masks are uint32 words, bit b of word w = base 32w + b of
  * the rank's concatenated reads; all calls are asynchronous on `hip_stream`.
  *   pack     d_mask[(n_bases+31)/32] <- (d_pml[k] == 0); d_pml 32-byte aligned
@@ -303,6 +304,23 @@ const char *colbwt_rlbwt_error(void);
  *            end at a read end or at total_words); d_pml needs room for whole
  *            32-value blocks and 64-byte alignment */
 int colbwt_pml_pack_device(const uint16_t *d_pml, uint64_t n_bases, uint32_t *d_mask, void *hip_stream);
+/* The col ids of the results are ids that rows of the table hold (col_bwt.hpp:513), and every rank
+ * holds the same table: they travel as codes of that dictionary, colbwt_cid_code_bits(n_ids) =
+ * max(1, ceil(log2(n_ids))) bits per base -- the same on every rank, so the gathers keep equal,
+ * known sizes -- laid out as bit planes: `bits` words per 32 bases, word p = bit p of the 32 codes.
+ * 7 distinct ids (the C2 index): 3 bits, so results travel at 0.5 bytes per base instead of 3.
+ *   dictionary  ids[0 .. *n_ids) <- the distinct col ids of the table's rows, ascending (ids: 256 bytes)
+ *   pack        d_planes[bits * (n_bases+31)/32] <- codes of d_cid[0 .. n_bases) (16-byte aligned);
+ *               `ids` is a HOST array (the dictionary), an id outside it packs as code 0
+ *   unpack      d_cid[32*first_word .. 32*(first_word+n_words)) <- ids of the codes in the planes of
+ *               those words (d_planes is the whole array: word w's planes at d_planes[bits * w]);
+ *               d_cid 32-byte aligned with room for whole 32-id blocks */
+int colbwt_index_cid_dictionary(const colbwt_index *idx, uint8_t *ids, uint32_t *n_ids);
+uint32_t colbwt_cid_code_bits(uint32_t n_ids);
+int colbwt_cid_pack_device(const uint8_t *d_cid, uint64_t n_bases, const uint8_t *ids, uint32_t n_ids, uint32_t *d_planes,
+                           void *hip_stream);
+int colbwt_cid_unpack_device(const uint32_t *d_planes, uint64_t first_word, uint64_t n_words, const uint8_t *ids, uint32_t n_ids,
+                             uint8_t *d_cid, void *hip_stream);
 int colbwt_read_end_mask_device(const uint64_t *d_read_off, uint64_t n_reads, uint32_t *d_mask, void *hip_stream);
 int colbwt_pml_unpack_device(const uint32_t *d_zero_mask, const uint32_t *d_end_mask, uint64_t first_word,
                              uint64_t n_words, uint64_t total_words, uint16_t *d_pml, void *hip_stream);

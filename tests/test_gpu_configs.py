@@ -8,7 +8,7 @@ failure paths the capacity configuration depends on.
       and the configuration's own size, 1 M reads (1e10 bases), on line rows: two runs and the
       three-step layout compared on the device, the oracle on the first, middle and last reads.
   C5  capacity: the largest indices one MI355X takes -- 1e9 rows opened with AUTO (line rows do
-      not fit: three-step rows, ~130 GB resident), 1.7e9 rows where the three-step refinement passes 2^32-2 rows and
+      not fit, which the build finds out after one counting pass: three-step rows, ~130 GB resident), 1.7e9 rows where the three-step refinement passes 2^32-2 rows and
       AUTO must settle for two-step rows -- plus the HBM-budget fallback and what a failed open
       leaves behind.
 Sizes shrink with COLBWT_TEST_ROWS / COLBWT_TEST_BIG_ROWS for rehearsals.
@@ -257,14 +257,28 @@ def test_hbm_budget_fallback_and_failed_open_leaves_nothing(pkg, oracle, c2_imag
         assert 24e9 < info.device_bytes < 27e9, info.device_bytes     # 31.9 GB with the one-step tables kept
     tbl.close()
     assert base - _free_hbm() < 64 << 20
-    tbl = pkg.ColPml.from_bytes(c2_image, layout=0)                  # no budget: AUTO = line rows, 8 look-ahead steps
+    tbl = pkg.ColPml.from_bytes(c2_image, layout=0)                  # no budget: AUTO = line rows + mismatch lines, K = 8
     info = tbl.info()
-    assert info.layout == 4 and info.layout_shape == (8 << 8 | 2)
+    assert info.layout == 5 and info.layout_shape >> 8 == 8
     if C2_ROWS == 200_000_000:
-        assert 0.9e9 < info.table_rows < 1.2e9 and 140e9 < info.device_bytes < 170e9, (info.table_rows, info.device_bytes)
+        assert 0.9e9 < info.table_rows < 1.2e9 and 180e9 < info.device_bytes < 205e9, (info.table_rows, info.device_bytes)
     _oracle_sample_check(pkg, ref, tbl, 200_000, 150, 9, 20_000)
     tbl.close()
     assert base - _free_hbm() < 64 << 20
+    # the ladder between the two (capi.hip): line rows without mismatch lines at K = 8, then shallower
+    if C2_ROWS == 200_000_000:
+        try:
+            for budget_gb, want in ((185, (8,)), (135, (6, 4))):
+                os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_gb * 1000)
+                tbl = pkg.ColPml.from_bytes(c2_image, layout=0)
+                info = tbl.info()
+                assert info.layout == 4 and info.layout_shape >> 8 in want, (budget_gb, info.layout, info.layout_shape >> 8)
+                assert info.device_bytes < budget_gb * 1000 * (1 << 20)
+                _oracle_sample_check(pkg, ref, tbl, 100_000, 150, 10, 10_000)
+                tbl.close()
+        finally:
+            os.environ.pop("COLBWT_HBM_BUDGET_MB", None)
+        assert base - _free_hbm() < 64 << 20
 
 
 def test_c5_capacity_auto_layout_1e9_rows(pkg, oracle):
