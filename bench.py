@@ -99,8 +99,10 @@ def main():
     n_chunks = args.chunks or (1 if world == 1 else 4)
     pml_bytes = d_pml.view(torch.uint8)[:2 * n_bases]
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    codec = None
+    codecs = []
     g_pml = None                                   # rank 0, packed gather: the rebuilt (world, bases) u16 values
+    g_cid = None                                   # ... and, with the col-id dictionary, the rebuilt col ids
+    cid_bits = 8
     if world > 1 and args.gather == "packed":
         words = (n_bases + 31) // 32
         d_zero = torch.zeros(words, dtype=torch.int32, device=dev)
@@ -119,12 +121,32 @@ def main():
             pkg.pml_unpack_device(g_zero[r].data_ptr(), d_end.data_ptr(), w0, nw, words, g_pml[r].data_ptr(),
                                   comm_stream.cuda_stream)
 
-        codec = multi_gpu.PmlCodec(d_zero.view(torch.uint8), pack, unpack, g_zero)
-        outputs = [(d_cid[:n_bases], 1)]
+        codecs.append(multi_gpu.PmlCodec(d_zero.view(torch.uint8), pack, unpack, g_zero))
+        # the col ids as codes of the table's dictionary of ids (every rank holds the same table)
+        ids = tbl.cid_dictionary()
+        cid_bits = pkg.cid_code_bits(len(ids))
+        if cid_bits <= 4:
+            d_planes = torch.zeros(cid_bits * words, dtype=torch.int32, device=dev)
+            g_planes = torch.zeros((world, 4 * cid_bits * words), dtype=torch.uint8, device=dev) if rank == 0 else None
+            if rank == 0:
+                g_cid = torch.zeros((world, words * 32), dtype=torch.uint8, device=dev)
+
+            def pack_cid(lo_base, nb):
+                pkg.cid_pack_device(d_cid.data_ptr() + lo_base, nb, ids, d_planes.data_ptr() + 4 * cid_bits * (lo_base // 32),
+                                    stream.cuda_stream)
+
+            def unpack_cid(r, w0, nw):
+                pkg.cid_unpack_device(g_planes[r].data_ptr(), w0, nw, ids, g_cid[r].data_ptr(), comm_stream.cuda_stream)
+
+            codecs.append(multi_gpu.PmlCodec(d_planes.view(torch.uint8), pack_cid, unpack_cid, g_planes, bits=cid_bits))
+            outputs = []
+        else:
+            cid_bits = 8
+            outputs = [(d_cid[:n_bases], 1)]
     else:
         outputs = [(pml_bytes, 2), (d_cid[:n_bases], 1)]
     pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, outputs, dev, (stream, comm_stream),
-                                    pml_codec=codec)
+                                    codecs=codecs)
     kernel_events = []
 
     def query_chunk(lo, hi):
@@ -170,9 +192,12 @@ def main():
         dist.gather(d_cid[:n_bases].contiguous(), rawc, dst=0)
         torch.cuda.synchronize()
         if rank == 0:
-            got_c = pipe.gathered[-1]
-            gather_ok = all(bool(torch.equal(got_c[r], rawc[r])) for r in range(world))
-            if codec:
+            if g_cid is not None:
+                gather_ok = all(bool(torch.equal(g_cid[r][:n_bases], rawc[r])) for r in range(world))
+            else:
+                got_c = pipe.gathered[-1]
+                gather_ok = all(bool(torch.equal(got_c[r], rawc[r])) for r in range(world))
+            if codecs:
                 gather_ok = gather_ok and all(bool(torch.equal(g_pml[r][:n_bases], raw[r])) for r in range(world))
             else:
                 gp = pipe.gathered[0].view(torch.int16)
@@ -234,7 +259,8 @@ def main():
                                    + ("" if is_baseline_cfg else " [REDUCED rehearsal size]"),
                        "rows": int(info.r), "reads_per_gpu": n_reads, "read_len": m,
                        "parallelism": (f"reads sharded x{world}, index replicated, RCCL gather to rank 0 "
-                                       + ("(PML as 1 bit/base + col ids: 1.125 B/base)" if codec else "(3 B/base)"))
+                                       + (f"(PML as 1 bit/base + col ids as {cid_bits} bits/base: {(1 + cid_bits) / 8:.3f} B/base)"
+                                          if codecs else "(3 B/base)"))
                        if world > 1 else "single GPU",
                        "gather_matches_plain_gather": gather_ok,
                        "pipeline_chunks": n_chunks,

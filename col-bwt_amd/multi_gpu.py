@@ -8,9 +8,10 @@ the per-base outputs to rank 0 (RCCL over xGMI: `torch.distributed` backend
 "nccl"), pipelined in chunks behind the compute so the links work while the
 next chunk is being queried.  The 16-bit PML values travel as ONE BIT per base
 (`PmlCodec`; include/colbwt.h "multi-GPU gather codec"): a read's values are
-determined by where they are zero, so 3 bytes per base become 1.125 and rank 0
-rebuilds the values on its own GPU -- rank 0's ingest over its 7 xGMI links is
-what limits the job at N = 8, not the query.
+determined by where they are zero; the col ids travel as codes of the table's
+own dictionary of ids (3 bits per base on the C2 index).  3 bytes per base
+become 0.5 and rank 0 rebuilds both arrays on its own GPU -- rank 0's ingest
+over its 7 xGMI links is what limits the job at N = 8, not the query.
 
 Everything here is backend-agnostic plumbing (also exercised with gloo on CPU
 tensors by tests/test_multi_gpu_gloo.py); the compute is injected as a callable.
@@ -41,19 +42,23 @@ def chunk_bounds(n_reads, n_chunks, align=1):
 
 
 class PmlCodec:
-    """One bit per base for the PML values on their way to rank 0 (fixed-length reads).
+    """A per-base array on its way to rank 0 as `bits` bits per base (fixed-length reads): 32 bases
+    are `bits` 32-bit words, so every chunk that starts on a 32-base word has a byte range of its
+    own in the packed array.  bits = 1: the PML values (a read's values are determined by where they
+    are zero); bits = colbwt_cid_code_bits(#ids): the col ids as codes of the table's dictionary.
 
-    The three callables get plain integers (element / word indices) and run on the
-    caller's current stream: the HIP kernels of csrc/gather_codec.hip on a GPU
-    (bench.py), numpy stand-ins in the gloo test.
-      pack(lo_base, n_bases)              local values -> local zero mask
-      unpack(r, first_word, n_words)      rank 0: gathered zero mask of rank r -> its values
-    `mask` is the local zero mask as a uint8 tensor of whole 32-bit words; on rank 0
-    `gathered_mask` is (world, mask.numel()) and the rebuilt values live with the caller.
+    The callables get plain integers (element / word indices) and run on the caller's current
+    stream: the HIP kernels of csrc/gather_codec.hip on a GPU (bench.py), numpy stand-ins in the
+    gloo test.
+      pack(lo_base, n_bases)              local values -> local packed words
+      unpack(r, first_word, n_words)      rank 0: gathered packed words of rank r -> its values
+    `mask` is the local packed array as a uint8 tensor of whole 32-bit words (4 * bits bytes per 32
+    bases); on rank 0 `gathered_mask` is (world, mask.numel()) and the rebuilt values live with the
+    caller.
     """
 
-    def __init__(self, mask, pack, unpack, gathered_mask=None):
-        self.mask, self.pack, self.unpack, self.gathered_mask = mask, pack, unpack, gathered_mask
+    def __init__(self, mask, pack, unpack, gathered_mask=None, bits=1):
+        self.mask, self.pack, self.unpack, self.gathered_mask, self.bits = mask, pack, unpack, gathered_mask, bits
 
 
 class GatherPipeline:
@@ -69,15 +74,16 @@ class GatherPipeline:
     """
 
     def __init__(self, dist, rank, world, n_reads, read_len, n_chunks, outputs, device, streams=None,
-                 pml_codec=None):
+                 pml_codec=None, codecs=None):
         import torch
         self.torch, self.dist = torch, dist
         self.rank, self.world = rank, world
         self.m = read_len
-        # with the codec a chunk must start on a 32-base word: 32 reads of any length do
-        self.bounds = chunk_bounds(n_reads, n_chunks, 32 if pml_codec else 1)
+        # arrays that travel packed (`codecs`; `pml_codec` = a list of one): a chunk must then start on
+        # a 32-base word, which 32 reads of any length do
+        self.codecs = list(codecs or []) + ([pml_codec] if pml_codec else [])
+        self.bounds = chunk_bounds(n_reads, n_chunks, 32 if self.codecs else 1)
         self.outputs = outputs
-        self.codec = pml_codec
         self.cuda = device.type == "cuda"
         self.compute_stream, self.comm_stream = streams if streams else (None, None)
         self.gathered = None
@@ -100,8 +106,8 @@ class GatherPipeline:
                 on_launch("after")
             if self.world == 1:
                 continue
-            if self.codec:
-                self.codec.pack(lo * self.m, (hi - lo) * self.m)
+            for codec in self.codecs:
+                codec.pack(lo * self.m, (hi - lo) * self.m)
             if self.cuda:
                 done = torch.cuda.Event()
                 done.record(self.compute_stream)
@@ -115,16 +121,17 @@ class GatherPipeline:
                     a, b = bpb * lo * self.m, bpb * hi * self.m
                     glist = [self.gathered[k][r, a:b] for r in range(self.world)] if self.rank == 0 else None
                     works.append(dist.gather(src[a:b], glist, dst=0, async_op=True))
-                if self.codec:
-                    w0, w1 = lo * self.m // 32, (hi * self.m + 31) // 32      # whole words of the chunk
-                    gm = self.codec.gathered_mask
-                    glist = [gm[r, 4 * w0:4 * w1] for r in range(self.world)] if self.rank == 0 else None
-                    work = dist.gather(self.codec.mask[4 * w0:4 * w1], glist, dst=0, async_op=True)
+                w0, w1 = lo * self.m // 32, (hi * self.m + 31) // 32          # whole words of the chunk
+                for codec in self.codecs:
+                    a, b = 4 * codec.bits * w0, 4 * codec.bits * w1
+                    gm = codec.gathered_mask
+                    glist = [gm[r, a:b] for r in range(self.world)] if self.rank == 0 else None
+                    work = dist.gather(codec.mask[a:b], glist, dst=0, async_op=True)
                     works.append(work)
                     if self.rank == 0:
                         work.wait()          # orders the comm stream behind the gather (blocks on gloo)
                         for r in range(self.world):
-                            self.codec.unpack(r, w0, w1 - w0)
+                            codec.unpack(r, w0, w1 - w0)
 
     def finish(self):
         """Waits for every outstanding gather (and, on a GPU, orders the compute stream behind the

@@ -158,6 +158,23 @@ def main():
     pkg.pml_unpack_device(zero.ctypes.data, last.ctypes.data, first, nw - first, nw, out.ctypes.data)
     assert np.array_equal(out[:nb], epml), np.flatnonzero(out[:nb] != epml)[:10]
     print(f"ok gather codec: {len(creads)} reads, {nb} bases, split at word {first}")
+    # ... and the col ids as codes of the table's dictionary of ids, bit planes
+    _, ecid = oracle.OracleIndex(bytes(img)).query_batch(cb, coff)
+    tblc = pkg.ColPml.from_bytes(bytes(img))
+    ids = tblc.cid_dictionary()
+    tblc.close()
+    assert ids.tolist() == sorted(set(helpers.unpack_col_pml(bytes(img))["cid"].tolist())) and set(ecid.tolist()) <= set(ids.tolist())
+    for dict_ids in (ids, np.arange(256, dtype=np.uint8)):
+        cbits = pkg.cid_code_bits(len(dict_ids))
+        d_cid = aligned(nw * 32, np.uint8)
+        d_cid[:nb] = ecid
+        planes = aligned(cbits * nw, np.uint32)
+        back = aligned(nw * 32, np.uint8)
+        pkg.cid_pack_device(d_cid.ctypes.data, nb, dict_ids, planes.ctypes.data)
+        pkg.cid_unpack_device(planes.ctypes.data, 0, first, dict_ids, back.ctypes.data)
+        pkg.cid_unpack_device(planes.ctypes.data, first, nw - first, dict_ids, back.ctypes.data)
+        assert np.array_equal(back[:nb], ecid), (cbits, np.flatnonzero(back[:nb] != ecid)[:10])
+    print(f"ok col-id codec: {len(ids)} ids in the table's dictionary, {pkg.cid_code_bits(len(ids))} bit planes")
 
     # 2. true BWT index, reads with substitutions, N and lowercase (no case folding)
     seqs = []
@@ -266,17 +283,21 @@ def main():
     bases, off = helpers.concat_reads(reads)
     epml, ecid = oracle.OracleIndex(bytes(img)).query_batch(bases, off)
     full = {}
-    for layout in (1, 2, 3, 4):
+    for layout in (1, 2, 3, 4, 5):
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         full[layout] = tbl.info().device_bytes
         tbl.close()
-    assert full[1] < full[2] < full[3] < full[4]
+    assert full[1] < full[2] < full[3] < full[4] < full[5]
     del os.environ["COLBWT_LAYOUT"]                   # the engine's own choice from here on
-    for budget_mb, expect in ((10_000, 4), (full[4] / 2**20 - 0.01, 3), (full[3] / 2**20 - 0.01, 2),
-                              (full[2] / 2**20 - 0.01, 1)):
+    # the ladder (capi.hip): mismatch lines, line rows at K = 8 / 6 / 4, three-, two-, one-step rows
+    for budget_mb, expect in ((10_000, (5,)), (full[5] / 2**20 - 0.01, (4,)), (full[4] / 2**20 - 0.01, (4, 3)),
+                              (full[3] / 2**20 - 0.01, (2,)), (full[2] / 2**20 - 0.01, (1,))):
         os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)
         tbl = pkg.ColPml.from_bytes(img, layout=0)
-        assert tbl.info().layout == expect, (budget_mb, tbl.info().layout, full)
+        info = tbl.info()
+        assert info.layout in expect and info.device_bytes <= budget_mb * 2**20, (budget_mb, info.layout, full)
+        if budget_mb < full[4] / 2**20 and info.layout == 4:
+            assert info.layout_shape >> 8 < 8              # not the depth that was just ruled out
         pml, cid, _ = tbl.query_batch(bases, off)
         assert np.array_equal(pml, epml) and np.array_equal(cid, ecid)
         tbl.close()

@@ -133,7 +133,8 @@ def test_c4_long_reads_all_layouts(pkg, oracle, c2_image):
 
 def test_c4_at_baseline_size_one_million_long_reads(pkg, oracle, c2_image):
     """BASELINE configs[3] at its own size: 1 M reads of 8-12 kbp (1e10 bases, 5 % substitutions,
-    backward walks on the 2e8-row index) on line rows -- five reads per persistent lane, so every
+    backward walks on the 2e8-row index) on the layout AUTO picks (line rows with mismatch lines) --
+    five reads per persistent lane, so every
     lane claims further chunks from its workgroup's counter and the last tenth of every share goes
     out read by read (fat_query.hip ChunkPlan; the 100 k-read case above never gets there).
     Two runs are compared ON THE DEVICE, then with the three-step layout's run on the same
@@ -149,8 +150,8 @@ def test_c4_at_baseline_size_one_million_long_reads(pkg, oracle, c2_image):
     off_np[1:] = np.cumsum(lens_np)
     nb = int(off_np[-1])
     _free_hbm()
-    tbl = pkg.ColPml.from_bytes(c2_image, layout=4)
-    assert tbl.info().layout == 4
+    tbl = pkg.ColPml.from_bytes(c2_image, layout=0)           # AUTO: line rows with mismatch lines
+    assert tbl.info().layout == 5
     d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
     d_off = torch.from_numpy(off_np).to(dev)
     d_fixed = torch.zeros(chunk * m_max + 128, dtype=torch.uint8, device=dev)
@@ -175,7 +176,7 @@ def test_c4_at_baseline_size_one_million_long_reads(pkg, oracle, c2_image):
     p2, c2, _ = run(tbl)
     assert torch.equal(p1, p2) and torch.equal(c1, c2)
     del p2, c2
-    print(f"C4 at BASELINE size: {n_reads} reads, {nb} bases, line rows {ms1:.1f} ms = {nb / ms1 / 1e6:.1f} Gbase/s")
+    print(f"C4 at BASELINE size: {n_reads} reads, {nb} bases, line rows + mismatch lines {ms1:.1f} ms = {nb / ms1 / 1e6:.1f} Gbase/s")
     # the oracle on the first, middle and last reads
     ref = oracle.OracleIndex(c2_image)
     per = max(1, min(n_reads // 3, 1_800))

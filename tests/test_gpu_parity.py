@@ -385,16 +385,17 @@ def test_concurrent_host_threads_share_one_index(pkg, oracle):
         assert np.array_equal(results[t][0], ep) and np.array_equal(results[t][1], ec)
 
 
-def test_many_overlapping_launches_on_one_index(pkg, oracle):
+@pytest.mark.parametrize("layout", [4, 5])
+def test_many_overlapping_launches_on_one_index(pkg, oracle, layout):
     """include/colbwt.h: any number of colbwt_query_device launches may be in flight on one index.
     48 asynchronous launches on 24 streams (two per stream, nothing waited for in between) against
-    one line-row index, each over a batch of its own large enough to run for a while and to claim
+    one line-row index (both kinds), each over a batch of its own large enough to run for a while and to claim
     chunks from the workgroups' counters; every result equals the oracle's."""
     import torch
     dev = torch.device("cuda", 0)
     image = pkg.synth_index(2_000_000, mean_len=8, split_permille=0, seed=42)
-    tbl = pkg.ColPml.from_bytes(image, layout=4)
-    assert tbl.info().layout == 4
+    tbl = pkg.ColPml.from_bytes(image, layout=layout)
+    assert tbl.info().layout == layout
     n_launch, n_streams, n_reads, m = 48, 24, 120_000, 150
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     d_bases = torch.zeros((n_launch, n_reads * m + 128), dtype=torch.uint8, device=dev)
@@ -522,8 +523,22 @@ def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
         lambda r, w0, nw: pkg.pml_unpack_device(g_zero[r].data_ptr(), d_end.data_ptr(), w0, nw, words,
                                                 g_pml[r].data_ptr(), comm.cuda_stream),
         g_zero)
+    # the col ids as codes of the table's dictionary (7 ids in the synthetic recipe: 3 bit planes)
+    ids = tbl.cid_dictionary()
+    assert ids.tolist() == sorted(set(helpers.unpack_col_pml(image.tobytes())["cid"].tolist()))
+    bits = pkg.cid_code_bits(len(ids))
+    assert bits == 3
+    d_planes = torch.zeros(bits * words, dtype=torch.int32, device=dev)
+    g_planes = torch.zeros((world, 4 * bits * words), dtype=torch.uint8, device=dev)
+    g_cid = torch.full((world, words * 32), 0xEE, dtype=torch.uint8, device=dev)
+    cid_codec = multi_gpu.PmlCodec(
+        d_planes.view(torch.uint8),
+        lambda lo_base, n: pkg.cid_pack_device(d_cid.data_ptr() + lo_base, n, ids, d_planes.data_ptr() + 4 * bits * (lo_base // 32),
+                                               stream.cuda_stream),
+        lambda r, w0, nw: pkg.cid_unpack_device(g_planes[r].data_ptr(), w0, nw, ids, g_cid[r].data_ptr(), comm.cuda_stream),
+        g_planes, bits=bits)
     pipe = multi_gpu.GatherPipeline(FakeDist, 0, world, n_reads, m, 4, [(d_cid[:nb], 1)], dev, (stream, comm),
-                                    pml_codec=codec)
+                                    codecs=[codec, cid_codec])
     assert pipe.bounds[0] == 0 and pipe.bounds[-1] == n_reads and all(b % 32 == 0 for b in pipe.bounds[:-1])
     for _ in range(2):
         pipe.step(query_chunk)
@@ -536,6 +551,17 @@ def test_gather_codec_round_trip_and_pipeline(pkg, oracle):
     for r in range(world):
         assert np.array_equal(g_pml[r][:nb].cpu().numpy().view(np.uint16), ep), r
         assert np.array_equal(pipe.gathered[0][r].cpu().numpy(), ec), r
+        assert np.array_equal(g_cid[r][:nb].cpu().numpy(), ec), r
+    # a dictionary of 200 ids (8 bit planes) round-trips as well
+    many = np.arange(3, 203, dtype=np.uint8)
+    src = torch.from_numpy(many[np.random.default_rng(5).integers(0, 200, size=words * 32)]).to(dev)
+    pl8 = torch.zeros(8 * words, dtype=torch.int32, device=dev)
+    back = torch.zeros(words * 32, dtype=torch.uint8, device=dev)
+    assert pkg.cid_code_bits(200) == 8 and pkg.cid_code_bits(1) == 1 and pkg.cid_code_bits(2) == 1 and pkg.cid_code_bits(17) == 5
+    pkg.cid_pack_device(src.data_ptr(), words * 32 - 5, many, pl8.data_ptr())
+    pkg.cid_unpack_device(pl8.data_ptr(), 0, words, many, back.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(back[:words * 32 - 5], src[:words * 32 - 5])
     tbl.close()
 
 

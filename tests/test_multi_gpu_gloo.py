@@ -88,13 +88,38 @@ def _worker(rank, world, port, n_reads, m, n_chunks, q, packed=False):
             gpml[r, 32 * w0:32 * (w0 + nw)] = _np_unpack(zb[:32 * (w0 + nw)], end_bits[:32 * (w0 + nw)])[32 * w0:]
 
         codec = multi_gpu.PmlCodec(mask, pack, unpack, gmask)
-        pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, [(cid, 1)], torch.device("cpu"),
-                                        pml_codec=codec)
+        # ... and the col ids as codes of the table's dictionary, `bits` bit planes per 32 bases
+        # (numpy stand-ins for cid_pack_kernel / cid_unpack_kernel of csrc/gather_codec.hip)
+        ids = np.unique(helpers.unpack_col_pml(image)["cid"])
+        bits = max(1, int(np.ceil(np.log2(len(ids)))))
+        code_of = np.zeros(256, np.uint8)
+        code_of[ids] = np.arange(len(ids))
+        planes = torch.zeros(4 * bits * words, dtype=torch.uint8)
+        gplanes = torch.zeros((world, 4 * bits * words), dtype=torch.uint8) if rank == 0 else None
+        gcid = np.zeros((world, words * 32), np.uint8)
+
+        def pack_cid(lo_base, n):
+            assert lo_base % 32 == 0
+            c = code_of[cid[lo_base:lo_base + n].numpy()]
+            c = np.concatenate((c, np.zeros((-n) % 32, np.uint8))).reshape(-1, 32)
+            pl = np.stack([np.packbits((c >> p) & 1, axis=1, bitorder="little") for p in range(bits)], axis=1)   # (words, bits, 4)
+            w0 = lo_base // 32
+            planes[4 * bits * w0:4 * bits * (w0 + len(c))] = torch.from_numpy(pl.reshape(-1))
+
+        def unpack_cid(r, w0, nw):
+            pl = gplanes[r].numpy()[4 * bits * w0:4 * bits * (w0 + nw)].reshape(nw, bits, 4)
+            codes = sum(np.unpackbits(pl[:, p], axis=1, bitorder="little").astype(np.uint8) << p for p in range(bits))
+            gcid[r, 32 * w0:32 * (w0 + nw)] = ids[np.minimum(codes, len(ids) - 1)].reshape(-1)
+
+        cid_codec = multi_gpu.PmlCodec(planes, pack_cid, unpack_cid, gplanes, bits=bits)
+        pipe = multi_gpu.GatherPipeline(dist, rank, world, n_reads, m, n_chunks, [], torch.device("cpu"),
+                                        codecs=[codec, cid_codec])
         pipe.step(query_chunk)
         pipe.step(query_chunk)      # buffers are reused across steps
         pipe.finish()
         gp = gpml[:, :nb].reshape(-1) if rank == 0 else None
-        gc = pipe.gathered[0].reshape(-1).numpy() if rank == 0 else None
+        gc = gcid[:, :nb].reshape(-1) if rank == 0 else None
+        assert bits < 8             # the synthetic table's ids: a handful of values
     if rank == 0:
         all_bases, all_off = helpers.concat_reads(reads)
         ep, ec = ref.query_batch(all_bases, all_off)

@@ -38,6 +38,25 @@ def main():
         b.record()
         torch.cuda.synchronize()
         res[name + "_ms"] = a.elapsed_time(b) / 5
+    # the col ids: 7 distinct values (the C2 recipe) -> 3 bit planes
+    ids = __import__("numpy").array([0, 1, 2, 3, 17, 200, 255], dtype="uint8")
+    cid = torch.from_numpy(ids)[torch.randint(0, 7, (words * 32,), generator=torch.Generator().manual_seed(2))].to(dev)
+    planes = torch.zeros(3 * words, dtype=torch.int32, device=dev)
+    back = torch.zeros(words * 32, dtype=torch.uint8, device=dev)
+    for name, fn in (("cid_pack", lambda: pkg.cid_pack_device(cid.data_ptr(), nb, ids, planes.data_ptr(), s)),
+                     ("cid_unpack", lambda: pkg.cid_unpack_device(planes.data_ptr(), 0, words, ids, back.data_ptr(), s))):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = a.elapsed_time(b) / 5
+    res["cid_round_trip_ok"] = bool(torch.equal(back[:nb], cid[:nb]))
+    res["cid_bits"] = 3
+    res["bytes_per_base_on_the_wire"] = (1 + 3) / 8
     res["bases"] = nb
     res["pack_GBps"] = (2 * nb + nb / 8) / res["pack_ms"] / 1e6
     res["unpack_GBps"] = (2 * nb + nb / 4) / res["unpack_ms"] / 1e6
