@@ -347,7 +347,7 @@ int query_batch_host(colbwt_index *idx, const uint8_t *bases, const uint64_t *re
     if (idx->ix.line_rows())
         launch_fat_query(idx->ix.table_fat(), d_bases, d_off, n_reads, n_bases, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
-        launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
+        launch_sk_query(idx->ix.table_k(), d_bases, d_off, n_reads, n_bases, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_off, n_reads, d_pml, (int)sizeof(PmlT), d_cid, d_order, stream);
     HOST_HIP(hipGetLastError());
@@ -712,7 +712,7 @@ int colbwt_query_device_ordered(colbwt_index *idx, const uint8_t *d_bases, const
     if (idx->ix.line_rows())
         launch_fat_query(idx->ix.table_fat(), d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, d_order, stream);
     else if (idx->ix.layout() >= 2)
-        launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
+        launch_sk_query(idx->ix.table_k(), d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, d_order, stream);
     else
         launch_pml_query(idx->ix.table(), d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     API_HIP(hipGetLastError());

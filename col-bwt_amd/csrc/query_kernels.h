@@ -25,8 +25,11 @@ void launch_pml_query(const DevTable &T, const uint8_t *d_bases, const uint64_t 
 namespace colbwt {
 
 // The same query over a K-step layout (sk_query.hip); K = T.steps.
-void launch_sk_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+void launch_sk_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                      void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream);
+// ... three-step rows with persistent lanes and pair-fetched rows (sk3_query.hip; launch_sk_query dispatches to it)
+void launch_sk3_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
+                      void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream);
 
 // ---- load-time kernels (index_kernels.hip) --------------------------------
 struct RelayoutReport {

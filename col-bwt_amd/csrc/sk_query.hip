@@ -12,6 +12,7 @@
 // as the reference would.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "device_layout.h"
 #include "lane_io.h"
@@ -211,9 +212,17 @@ void launch_k(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_o
 
 }  // namespace
 
-void launch_sk_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads,
+void launch_sk_query(const SKTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                      void *d_pml, int pml_bytes, uint8_t *d_cid, const uint32_t *d_order, hipStream_t stream) {
     if (n_reads == 0) return;
+    // three-step rows: the kernel with persistent lanes and pair-fetched rows (sk3_query.hip); the one
+    // below remains for two-step rows (24-byte rows do not split into 16-byte pieces) and, with
+    // COLBWT_SK3_ROUND1=1, for A/B runs
+    static const bool round1 = getenv("COLBWT_SK3_ROUND1") != nullptr;
+    if (T.steps == 3 && !round1) {
+        launch_sk3_query(T, d_bases, d_read_off, n_reads, n_bases, d_pml, pml_bytes, d_cid, stream);
+        return;
+    }
     if (T.steps == 3) launch_k<3>(T, d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
     else launch_k<2>(T, d_bases, d_read_off, n_reads, d_pml, pml_bytes, d_cid, d_order, stream);
 }

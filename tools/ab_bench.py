@@ -46,12 +46,13 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--pml-bytes", type=int, default=2, help="2 = u16 PML (reads <= 65535 bases), 4 = u32")
     ap.add_argument("--thr-mode", type=int, default=0, help="0: thresholds uniform in [0,n) (C2 recipe); 1: between runs")
+    ap.add_argument("--split-permille", type=int, default=0, help="rows that are sub-run splits (C5: 100)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     import torch
     pkg = load_package()
     dev = torch.device("cuda", 0)
-    image = pkg.synth_index(a.rows, 8, 0, 42, a.thr_mode)
+    image = pkg.synth_index(a.rows, 8, a.split_permille, 42, a.thr_mode)
     n_reads, m = a.reads, a.read_len
     nb = n_reads * m
     d_bases = torch.zeros(nb + 128, dtype=torch.uint8, device=dev)
@@ -67,13 +68,16 @@ def main():
         h = C.c_void_p()
         rc = L.colbwt_index_open_memory_layout(image.ctypes.data, image.size, None, 0, layout_arg(lay), C.byref(h))
         assert rc == 0, L.colbwt_last_error()
-        variants.append((os.path.basename(spec), L, h, []))
-    name0, L0, h0, _ = variants[0]
+        info = pkg.Info()
+        L.colbwt_index_info(h, C.byref(info))
+        variants.append((os.path.basename(spec), L, h, [], {"layout": int(info.layout), "steps": int(info.layout_shape >> 8),
+                                                             "table_rows": int(info.table_rows), "hbm_GB": round(info.device_bytes / 1e9, 1)}))
+    name0, L0, h0, _, _ = variants[0]
     assert L0.colbwt_synth_reads_device(h0, n_reads, m, a.sub_permille, 43, d_bases.data_ptr(), d_off.data_ptr(), None) == 0
     torch.cuda.synchronize()
     sums = {}
     for rep in range(a.reps + 1):
-        for name, L, h, times in variants:
+        for name, L, h, times, _ in variants:
             d_pml = torch.zeros(nb + 16, dtype=torch.int16 if a.pml_bytes == 2 else torch.int32, device=dev)
             d_cid = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
             st = Stats()
@@ -88,13 +92,13 @@ def main():
     ref = sums[variants[0][0]]
     # a checksum only says something when there is another variant to compare with: with a single
     # variant it would be compared with itself -- null then (results are checked in tests/, not here)
-    for k, (name, L, h, times) in enumerate(variants):
+    for k, (name, L, h, times, shape) in enumerate(variants):
         print(json.dumps({"lib": name, "ms": round(float(np.mean(times)), 3), "min_ms": round(min(times), 3),
                           "Gbase_s": round(nb / np.mean(times) / 1e6, 3),
                           "checksum_ok": (sums[name] == ref) if len(variants) > 1 else None,
                           "checksum_against": variants[0][0] if len(variants) > 1 and k else None,
                           "checksum": list(sums[name]),   # sums of all PML values / col ids: comparable across processes
-                          "rows": a.rows, "reads": n_reads, "read_len": m, "pml_bytes": a.pml_bytes}), flush=True)
+                          "index": shape, "rows": a.rows, "reads": n_reads, "read_len": m, "pml_bytes": a.pml_bytes}), flush=True)
 
 
 if __name__ == "__main__":
