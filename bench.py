@@ -218,7 +218,7 @@ def main():
         line_fills = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         is_baseline_cfg = (args.rows, args.reads, args.read_len) == (200_000_000, 10_000_000, 150)
-        kernel_name = (f"fat2_query_kernel<{info.layout_shape >> 8},u16>" if info.layout == 5
+        kernel_name = (f"fat2_query_kernel<{info.layout_shape >> 8},u16,{'deep' if info.layout == 6 else 'plain'}>" if info.layout in (5, 6)
                        else f"fat_query_kernel<{info.layout_shape >> 8},u16>" if info.layout == 4
                        else f"sk_query_kernel<{info.layout},u16>" if info.layout >= 2 else "pml_query_kernel<u16>")
         if is_baseline_cfg and n_chunks == 1 and os.path.exists(tpath):
@@ -241,12 +241,12 @@ def main():
                 # 128-byte line fills, measured by tools/gather_littles.sh for this access shape.
                 rd, wr = tj["read_requests_per_launch"], tj["write_requests_per_launch"]
                 sec = avg_launch_ms * 1e-3
-                ceiling = GATHER_CEILING_LINE_G if info.layout in (4, 5) else GATHER_CEILING_G
+                ceiling = GATHER_CEILING_LINE_G if info.layout in (4, 5, 6) else GATHER_CEILING_G
                 line_fills = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
                               "achieved_G_per_s": rd / sec / 1e9, "write_G_per_s": wr / sec / 1e9,
                               "ceiling_G_per_s": ceiling, "frac": rd / sec / 1e9 / ceiling,
                               "ceiling_source": ("profiles/r02_gather_line_rows.jsonl (dependent random whole lines, "
-                                                 "lane-cooperative LDS-DMA, reads only)" if info.layout in (4, 5) else
+                                                 "lane-cooperative LDS-DMA, reads only)" if info.layout in (4, 5, 6) else
                                                  "profiles/r01_gather_littles_16GiB.jsonl (dependent random 2x16 B "
                                                  "loads per line, reads only)")}
         out = {
@@ -268,7 +268,8 @@ def main():
                        "index_hbm_bytes": int(info.device_bytes),
                        "hbm_layout": {1: "one-step", 2: "two-step", 3: "three-step",
                                       4: f"line rows K={info.layout_shape >> 8} KS={info.layout_shape & 255}",
-                                      5: f"line rows K={info.layout_shape >> 8} + mismatch lines"}.get(info.layout, "?"),
+                                      5: f"line rows K={info.layout_shape >> 8} + mismatch lines",
+                                      6: f"line rows K={info.layout_shape >> 8} + deep mismatch lines"}.get(info.layout, "?"),
                        "hbm_table_rows": int(info.table_rows)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -325,7 +326,7 @@ def main():
                 import subprocess
                 tbl.close()                      # the calibration table needs the HBM the index holds
                 torch.cuda.empty_cache()
-                gb_args = ["65536", "196608", "1500", "16", "2", "0"] if info.layout in (4, 5) else ["16384", "524288", "1500", "10", "2", "0"]
+                gb_args = ["65536", "196608", "1500", "16", "2", "0"] if info.layout in (4, 5, 6) else ["16384", "524288", "1500", "10", "2", "0"]
                 res = subprocess.run([gb] + gb_args, capture_output=True, text=True, timeout=120)
                 rates = [json.loads(line)["Gsteps_per_s"] for line in res.stdout.splitlines() if line.startswith("{")]
                 if rates:
@@ -333,7 +334,7 @@ def main():
                     lf["frac"] = lf["achieved_G_per_s"] / lf["ceiling_G_per_s"]
                     lf["ceiling_source"] = "tools/gather_bench on this box, after the timed region " + (
                         "(dependent random whole 128-byte lines, lane-cooperative LDS-DMA, 64 GiB table, reads only)"
-                        if info.layout in (4, 5) else
+                        if info.layout in (4, 5, 6) else
                         "(dependent random loads of one aligned 32-byte row = 2 x 16 B, 16 GiB table, reads only)")
             except Exception as e:      # the calibration is optional: keep the recorded constant
                 lf["ceiling_note"] = f"live calibration failed: {e}"

@@ -30,7 +30,7 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_MISMATCH_LINES
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_MISMATCH_LINES_DEEP
 constexpr int kDefaultLineSteps = 8;
 
 // Device buffers, stream and events of one host-entry query, kept with the handle between calls
@@ -520,7 +520,7 @@ const char *colbwt_last_error(void) { return g_err.c_str(); }
 
 static int default_layout() {
     const char *e = getenv("COLBWT_LAYOUT");   // override: 1 = one-step, 2 / 3 = K-step rows, 4 = line rows
-    if (e && e[0] >= '1' && e[0] <= '5' && e[1] == 0) return e[0] - '0';
+    if (e && e[0] >= '1' && e[0] <= '6' && e[1] == 0) return e[0] - '0';
     return COLBWT_LAYOUT_DEFAULT_CHOICE;
 }
 
@@ -549,7 +549,7 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     const int steps = line_rows_steps(layout);
     const bool steps_given = ((layout >> 8) & 0xFF) != 0 || getenv("COLBWT_LINE_ROWS_STEPS") != nullptr;
     layout &= 0xFF;
-    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_MISMATCH_LINES) return fail(COLBWT_ERR_ARG, "bad layout");
+    if (layout < COLBWT_LAYOUT_ONE_STEP || layout > COLBWT_LAYOUT_MISMATCH_LINES_DEEP) return fail(COLBWT_ERR_ARG, "bad layout");
     if (layout >= COLBWT_LAYOUT_LINE_ROWS && !fat_steps_supported(steps))
         return fail(COLBWT_ERR_ARG, "line rows: own steps must be 4..8");
     *out = nullptr;
@@ -561,12 +561,14 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
     if (rc == COLBWT_ERR_NOMEM && automatic) {
         // The table does not fit that way (HBM, or more than 2^32-2 refined rows): the ladder of
-        // smaller layouts -- mismatch lines, line rows at K = 8, 6, 4, three-, two-, one-step rows.
+        // smaller layouts -- deep mismatch lines, mismatch lines, line rows at K = 8, 6, 4, three-, two-,
+        // one-step rows.
         // A line-row build says at which refinement level it gave up (after that level's counting
         // pass, before anything of it was allocated): candidates that have to pass the same level
         // are not tried at all, so an index far too large for line rows costs one counting pass.
         struct Candidate { int layout, steps; };
-        static const Candidate ladder[] = {{COLBWT_LAYOUT_MISMATCH_LINES, 8}, {COLBWT_LAYOUT_LINE_ROWS, 8}, {COLBWT_LAYOUT_LINE_ROWS, 6},
+        static const Candidate ladder[] = {{COLBWT_LAYOUT_MISMATCH_LINES_DEEP, 8}, {COLBWT_LAYOUT_MISMATCH_LINES, 8},
+                                           {COLBWT_LAYOUT_LINE_ROWS, 8}, {COLBWT_LAYOUT_LINE_ROWS, 6},
                                            {COLBWT_LAYOUT_LINE_ROWS, 4},      {COLBWT_LAYOUT_THREE_STEP, 0}, {COLBWT_LAYOUT_TWO_STEP, 0},
                                            {COLBWT_LAYOUT_ONE_STEP, 0}};
         int hopeless_from = layout >= COLBWT_LAYOUT_LINE_ROWS ? idx->ix.fat_failed_level() : 0;   // steps >= this cannot be built

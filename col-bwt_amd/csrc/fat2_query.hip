@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t mis_slot(uint32_t top4, uint32_t own, uint32
     return cidx < 4 && slot < kFatSlots ? slot : kFatSlots;
 }
 
-template <int K, typename PmlT>
+template <int K, typename PmlT, bool kDeep>
 __global__ __launch_bounds__(kQueryBlock)
 void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ read_off,
                        uint64_t n_reads, uint32_t big_reads, uint32_t tail_permille,
@@ -147,7 +147,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
         const uint32_t have = live ? win.avail(g) : 0u;      // read bytes at hand
         // what the trip reports: `consumed` bases, lengths l_new - e for element e (keep = 0: all 0),
         // col ids byte e of `ids`; pushed once below, whatever kind of line the lane had
-        uint32_t consumed = 0, l_new = 0, keep = 0xFFFFFFFFu;
+        uint32_t consumed = 0, l_new = 0, keep = 0xFFFFFFFFu, keep1 = 0xFFFFFFFFu;
         uint64_t ids = 0;
         if (!live || have == 0) FAT2_STAT(5);
         if (live && have != 0) {
@@ -157,7 +157,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                 // ---- a mismatch entry: the next base did not match where the lane came from
                 // (col_bwt.hpp:520-523: length 0, threshold_step, LF), the one after it is open
                 FAT2_STAT(2);
-                const uint32_t h4 = o == kOffMis1 ? 4u : 0u;
+                const uint32_t h4 = !kDeep && o == kOffMis1 ? 4u : 0u;      // a deep entry is the whole line
                 const uint4 e0 = my_row[(h4 + 0u) ^ p], e1 = my_row[(h4 + 1u) ^ p], e2 = my_row[(h4 + 2u) ^ p],
                             e3 = my_row[(h4 + 3u) ^ p];
                 const uint32_t carry = L;                    // col id of the row the mismatch happened in (:513)
@@ -180,21 +180,42 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                     keep = oc == 0 ? 0xFFFFFFFFu : 0u;       // ... (0, 0) when it is a mismatch of its own
                     ids = (uint64_t)(d1 | (carry << 8));
                     L = oc == 0 ? 1u : 0u;
-                    if (k > 2) {
-                        // the base after the two: does it match where the lane lands?
-                        uint32_t s3 = kFatSlots;
-                        if (left >= 3) {
-                            const uint32_t c3 = (uint32_t)(W >> 40) & 0xFFu;
-                            if (c3 != ch) s3 = mis_slot(T.top4, ch, c3);
+                    // what the lane stands on after the bases it consumed, and what it knows about the next one
+                    uint32_t nJ = J, nP = P, nrho = rho, nch = ch, ncd = cd, nv = vo, seen = 2;
+                    if constexpr (kDeep) {
+                        if (left >= 3 && ((uint32_t)(W >> 40) & 0xFFu) == ch) {
+                            // the base after the two matches what the landing meets (:516-517): resolved here too
+                            const uint4 f0 = my_row[4u ^ p], f1 = my_row[5u ^ p], f2 = my_row[6u ^ p], f3 = my_row[7u ^ p];
+                            nJ = oc == 0 ? f0.x : oc == 1 ? f0.y : oc == 2 ? f0.z : f0.w;
+                            nrho = oc == 0 ? f1.x : oc == 1 ? f1.y : oc == 2 ? f1.z : f1.w;
+                            const uint32_t pw2 = oc < 2 ? f2.x : f2.y;
+                            nP = (oc & 1u) ? pw2 >> 16 : pw2 & 0xFFFFu;
+                            nch = (f2.z >> (8 * oc)) & 0xFFu;
+                            ncd = (f2.w >> (8 * oc)) & 0xFFu;
+                            nv = (f3.x >> (4 * oc)) & 7u;
+                            consumed = 3;
+                            seen = 3;
+                            ids = (uint64_t)(cd | (d1 << 8) | (carry << 16));
+                            if (oc == 0) { l_new = 2; keep = 0xFFFFFFFFu; }            // (2, 1, 0)
+                            else { l_new = 1; keep = 0xFFFFFFFFu; keep1 = 0u; }        // (1, 0, 0)
+                            L += 1;
                         }
-                        if (s3 < kFatSlots && ((vo >> s3) & 1u)) {
-                            const uint32_t e = rho * kFatSlots + s3;     // straight on to the next entry
-                            j = T.slot_line0 + (e >> 1);
-                            o = kOffMis0 - (e & 1u);
-                            L = cd;
+                    }
+                    if (k > consumed) {
+                        // the base after those: does it match where the lane lands?
+                        uint32_t sn = kFatSlots;
+                        if (left > seen) {
+                            const uint32_t cn = (uint32_t)(W >> (8u * (7u - seen))) & 0xFFu;
+                            if (cn != nch) sn = mis_slot(T.top4, nch, cn);
+                        }
+                        if (sn < kFatSlots && ((nv >> sn) & 1u)) {
+                            const uint32_t e = nrho * kFatSlots + sn;    // straight on to the next entry
+                            j = T.slot_line0 + (kDeep ? e : e >> 1);
+                            o = kDeep ? kOffMis0 : kOffMis0 - (e & 1u);
+                            L = ncd;
                         } else {
-                            j = J;                           // exact: one position, fast-forward included
-                            o = P;
+                            j = nJ;                          // exact: one position, fast-forward included
+                            o = nP;
                         }
                     }
                 } else {
@@ -280,8 +301,8 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                         // the read is done: its last LF (:527) has no observable effect
                     } else if (to_entry) {
                         FAT2_STAT(6);
-                        j = T.slot_line0 + (e_next >> 1);
-                        o = kOffMis0 - (e_next & 1u);
+                        j = T.slot_line0 + (kDeep ? e_next : e_next >> 1);
+                        o = kDeep ? kOffMis0 : kOffMis0 - (e_next & 1u);
                         L = carry;
                     } else if (own_jump) {
                         // LF^steps lands at (I, O + o) ... unless the cuts say it is already further on
@@ -307,11 +328,11 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
             // ---- report the run (:525): element e is the base at g - consumed + 1 + e
             if constexpr (kWide) {
                 for (uint32_t e = 0; e < consumed; ++e) {
-                    pml[g - consumed + 1 + e] = (PmlT)(keep ? l_new - e : 0u);
+                    pml[g - consumed + 1 + e] = (PmlT)((e < 2 ? keep : keep1) ? l_new - e : 0u);
                     cid[g - consumed + 1 + e] = (uint8_t)(ids >> (8 * e));
                 }
             } else {
-                acc_pml.push_run(consumed, l_new, keep);
+                acc_pml.push_run(consumed, l_new, keep, keep1);
                 acc_cid.push_run(consumed, (uint32_t)ids, (uint32_t)(ids >> 32));
             }
             k -= consumed;
@@ -330,14 +351,14 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
 }
 
 // Blocks that are resident at once on the device (LDS-bound: 3 per CU): the persistent grid.
-template <int K, typename PmlT>
+template <int K, typename PmlT, bool kDeep>
 uint32_t resident_blocks2() {
     static uint32_t cached[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     if (cached[dev] == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fat2_query_kernel<K, PmlT>, kQueryBlock, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fat2_query_kernel<K, PmlT, kDeep>, kQueryBlock, 0) != hipSuccess || per_cu < 1)
             per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 1;
         (void)hipGetLastError();
@@ -346,11 +367,11 @@ uint32_t resident_blocks2() {
     return cached[dev];
 }
 
-template <int K, typename PmlT>
+template <int K, typename PmlT, bool kDeep>
 void launch_typed2(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                    PmlT *d_pml, uint8_t *d_cid, hipStream_t stream) {
     const uint64_t want_blocks = (n_reads + kQueryBlock - 1) / kQueryBlock;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want_blocks, resident_blocks2<K, PmlT>());
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(want_blocks, resident_blocks2<K, PmlT, kDeep>());
     // chunk sizes as in fat_query.hip (launch_typed)
     const uint64_t lanes = (uint64_t)blocks * kQueryBlock;
     const uint64_t avg_len = std::max<uint64_t>(n_bases / std::max<uint64_t>(n_reads, 1), 1);
@@ -361,15 +382,18 @@ void launch_typed2(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_
         if (v >= 1 && v <= 1024) big = (uint32_t)v;
         if (const char *c = strchr(e, ',')) tail_permille = (uint32_t)std::min(1000, std::max(0, atoi(c + 1)));
     }
-    hipLaunchKernelGGL((fat2_query_kernel<K, PmlT>), dim3(blocks), dim3(kQueryBlock), 0, stream, T, d_bases, d_read_off, n_reads,
+    hipLaunchKernelGGL((fat2_query_kernel<K, PmlT, kDeep>), dim3(blocks), dim3(kQueryBlock), 0, stream, T, d_bases, d_read_off, n_reads,
                        big, tail_permille, d_pml, d_cid);
 }
 
 template <int K>
 void launch_steps2(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,
                    void *d_pml, int pml_bytes, uint8_t *d_cid, hipStream_t stream) {
-    if (pml_bytes == 2) launch_typed2<K, uint16_t>(T, d_bases, d_read_off, n_reads, n_bases, (uint16_t *)d_pml, d_cid, stream);
-    else launch_typed2<K, uint32_t>(T, d_bases, d_read_off, n_reads, n_bases, (uint32_t *)d_pml, d_cid, stream);
+    const bool deep = T.entry_shift == 7;
+    if (pml_bytes == 2 && deep) launch_typed2<K, uint16_t, true>(T, d_bases, d_read_off, n_reads, n_bases, (uint16_t *)d_pml, d_cid, stream);
+    else if (pml_bytes == 2) launch_typed2<K, uint16_t, false>(T, d_bases, d_read_off, n_reads, n_bases, (uint16_t *)d_pml, d_cid, stream);
+    else if (deep) launch_typed2<K, uint32_t, true>(T, d_bases, d_read_off, n_reads, n_bases, (uint32_t *)d_pml, d_cid, stream);
+    else launch_typed2<K, uint32_t, false>(T, d_bases, d_read_off, n_reads, n_bases, (uint32_t *)d_pml, d_cid, stream);
 }
 
 }  // namespace

@@ -314,14 +314,16 @@ __global__ __launch_bounds__(256) void fat_pack_kernel(PlainLevel P, FatTable T,
 
 // One thread per mismatch entry e = 3 * origin row + slot (fat_layout.h): p_c of the origin row,
 // q1 = LF(p_c), and the landing after the NEXT base for each thing that base can do.
+template <bool kDeep>
 __global__ __launch_bounds__(256) void fat_mis_pack_kernel(PlainLevel P, FatTable T, const uint32_t *__restrict__ rho,
                                                            const uint32_t *__restrict__ rho_first,
                                                            const uint8_t *__restrict__ sflags, uint8_t *__restrict__ entries) {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (uint64_t)T.n_rho * kFatSlots) return;
-    uint32_t w[kMisBytes / 4];
+    constexpr uint32_t kDwords = (kDeep ? 2 * kMisBytes : kMisBytes) / 4;
+    uint32_t w[kDwords];
 #pragma unroll
-    for (uint32_t q = 0; q < kMisBytes / 4; ++q) w[q] = 0;
+    for (uint32_t q = 0; q < kDwords; ++q) w[q] = 0;
     const uint32_t i = rho_first[e / kFatSlots], slot = (uint32_t)(e % kFatSlots);
     if ((sflags[i] >> slot) & 1u) {
         const uint32_t a_dense = T.cmap[P.meta[i] & 0xFFu];
@@ -350,11 +352,21 @@ __global__ __launch_bounds__(256) void fat_mis_pack_kernel(PlainLevel P, FatTabl
             put_byte(w, 4 * kMisCh + o, m & 0xFFu);
             put_byte(w, 4 * kMisCid + o, m >> 8);
             w[kMisVal] |= (uint32_t)(sflags[j] & 7u) << (4 + 4 * o);
+            if constexpr (kDeep) {                                                // one more step, should the next base match
+                plain_lf(P, j, t);
+                const uint32_t m2 = P.meta[j];
+                w[kMisDeep + kMisJ - 2 + o] = j;
+                w[kMisDeep + kMisRho - 2 + o] = rho[j];
+                put_half(w, 4 * (kMisDeep + kMisP - 2) + 2 * o, (uint32_t)t);
+                put_byte(w, 4 * (kMisDeep + kMisCh - 2) + o, m2 & 0xFFu);
+                put_byte(w, 4 * (kMisDeep + kMisCid - 2) + o, m2 >> 8);
+                w[kMisDeep + kMisVal - 2] |= (uint32_t)(sflags[j] & 7u) << (4 * o);
+            }
         }
     }
-    uint4 *dst = reinterpret_cast<uint4 *>(entries + e * kMisBytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(entries + e * (kDwords * 4));
 #pragma unroll
-    for (uint32_t q = 0; q < kMisBytes / 16; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (uint32_t q = 0; q < kDwords / 4; ++q) dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 // One refinement pass into the plain form.  COLBWT_OK / COLBWT_ERR_NOMEM (HBM, row limit) /
@@ -412,7 +424,7 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
 }
 
 template <int K>
-int build_fat_steps(const DevTable &T1, const HintChars &chars, bool mismatch_lines, FatTable &out, FatBuffers &buf, std::string &err,
+int build_fat_steps(const DevTable &T1, const HintChars &chars, int mismatch_lines, FatTable &out, FatBuffers &buf, std::string &err,
                     const std::function<void()> &source_done, int &failed_level) {
     failed_level = 2;
     const uint8_t *cmap = T1.cmap;
@@ -502,13 +514,15 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, bool mismatch_li
             const int rc = exclusive_scan_u32(d_rho, r, n_rho, err);
             if (rc != COLBWT_OK) return rc;
         }
-        mis_lines = (n_rho * kFatSlots * kMisBytes + kFatRowBytes - 1) / kFatRowBytes;
+        const uint32_t entry_shift = mismatch_lines == 2 ? 7u : 6u;           // 2: deep entries, a line each
+        mis_lines = ((n_rho * kFatSlots << entry_shift) + kFatRowBytes - 1) / kFatRowBytes;
         if ((uint64_t)r + 1 + mis_lines > 0xFFFFFFFEull) {
             err = "line rows + mismatch lines need " + std::to_string((uint64_t)r + 1 + mis_lines) + " lines (> 2^32-2)";
             return COLBWT_ERR_NOMEM;
         }
         out.n_rho = (uint32_t)n_rho;
         out.slot_line0 = r + 1;
+        out.entry_shift = entry_shift;
         SK_TRY(rho_first_buf.alloc((n_rho + 1) * sizeof(uint32_t)));
         SK_TRY(sflags_buf.alloc((uint64_t)r + 1));
         d_rho_first = rho_first_buf.as<uint32_t>();
@@ -532,8 +546,12 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, bool mismatch_li
         uint8_t *const d_entries = d_lines + ((uint64_t)r + 1) * kFatRowBytes;
         if (mis_lines) SK_TRY(hipMemset(d_entries + (mis_lines - 1) * kFatRowBytes, 0, kFatRowBytes));   // the odd half of the last line
         const uint64_t n_entries = (uint64_t)out.n_rho * kFatSlots;
-        hipLaunchKernelGGL(fat_mis_pack_kernel, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, 0, cur, out,
-                           (const uint32_t *)d_rho, (const uint32_t *)d_rho_first, (const uint8_t *)d_sflags, d_entries);
+        if (mismatch_lines == 2)
+            hipLaunchKernelGGL(fat_mis_pack_kernel<true>, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, 0, cur, out,
+                               (const uint32_t *)d_rho, (const uint32_t *)d_rho_first, (const uint8_t *)d_sflags, d_entries);
+        else
+            hipLaunchKernelGGL(fat_mis_pack_kernel<false>, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, 0, cur, out,
+                               (const uint32_t *)d_rho, (const uint32_t *)d_rho_first, (const uint8_t *)d_sflags, d_entries);
     } else {
         hipLaunchKernelGGL((fat_pack_kernel<K, false>), dim3(nblocks), dim3(256), 0, 0, cur, out, (const uint32_t *)nullptr,
                            (const uint8_t *)nullptr, d_lines);
@@ -601,7 +619,7 @@ bool fat_steps_supported(int steps) {
 
 // Builds the line-row layout with `steps` own steps from the one-step tables.  Same contract as
 // build_sk.
-int build_fat(const DevTable &T, const HintChars &chars, int steps, bool mismatch_lines, FatTable &out, FatBuffers &buf,
+int build_fat(const DevTable &T, const HintChars &chars, int steps, int mismatch_lines, FatTable &out, FatBuffers &buf,
               std::string &err, const std::function<void()> &source_done, int *failed_level) {
     int rc = COLBWT_ERR_ARG, level = 0;
     err = "unsupported number of line-row steps";

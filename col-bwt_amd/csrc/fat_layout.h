@@ -64,6 +64,13 @@
 //   [10..11] P[0..3] halfwords | [12] ch[0..3] bytes | [13] cid[0..3] bytes |
 //   [14] v1 | vo[0] << 4 | vo[1] << 8 | vo[2] << 12 | vo[3] << 16 (3 valid bits each) | [15] 0.
 //   outcome 0 = the next base matches t1; outcome 1 + s = it is slot character s of q1's origin row.
+// DEEP entries (COLBWT_LAYOUT_MISMATCH_LINES_DEEP; entry_shift = 7): a whole line per entry, the first
+// 64 bytes as above, the second half one more step for every outcome -- if the base after the two
+// MATCHES the character the outcome's landing meets, it is resolved too: dwords [16..19] J2[0..3]
+// (landing after it) | [20..23] rho2[0..3] | [24..25] P2[0..3] halfwords | [26] ch2[0..3] |
+// [27] cid2[0..3] | [28] v2[o] << 4 o: what is met THERE, for the base after that.  Between two
+// mismatches of a stretch there is often exactly one matching base; with it resolved in the entry
+// the lane goes from entry to entry without the row visit in between.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -88,6 +95,7 @@ constexpr uint32_t kFatSlotP = 8, kFatSlotCh2 = 12, kFatSlotCid2 = 13;
 constexpr uint32_t kFatVal = 28, kFatRho = 80;
 // a mismatch entry
 constexpr uint32_t kMisBytes = 64, kMisJ1 = 0, kMisP1 = 1, kMisJ = 2, kMisRho = 6, kMisP = 10, kMisCh = 12, kMisCid = 13, kMisVal = 14;
+constexpr uint32_t kMisDeep = 16;        // dword offset of the second half of a deep entry: the same fields one step further
 
 struct FatTable {
     const uint8_t *lines;     // r rows of 128 bytes (+ one zero row)
@@ -105,6 +113,7 @@ struct FatTable {
     uint32_t top4;            // the four most frequent characters, byte k = dense index k
     uint32_t slot_line0;      // mismatch-line variant: line number (128-byte units of `lines`) of entry 0; 0 = in-row slots
     uint32_t n_rho;           // origin rows (entries: 3 per origin row)
+    uint32_t entry_shift;     // log2 of the bytes per mismatch entry: 6, or 7 = deep entries
 };
 
 // byte / halfword / dword k of a row image held as dwords

@@ -28,14 +28,14 @@ public:
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
     // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1);
-    // 4 = line rows (fat_layout.h) with `steps` own steps; 5 = the same with mismatch lines.
+    // 4 = line rows (fat_layout.h) with `steps` own steps; 5 = the same with mismatch lines; 6 = with deep ones.
     int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err, int steps = 0);
 
     const DevTable &table() const { return tbl_; }
     const SKTable &table_k() const { return tblk_; }
     const FatTable &table_fat() const { return tblf_; }
     int layout() const { return layout_; }
-    bool line_rows() const { return layout_ == 4 || layout_ == 5; }
+    bool line_rows() const { return layout_ >= 4 && layout_ <= 6; }
     uint64_t table_rows() const { return line_rows() ? tblf_.r : (layout_ >= 2 ? tblk_.r : tbl_.r); }
     int device() const { return device_; }
     uint64_t bwt_r() const { return bwt_r_; }

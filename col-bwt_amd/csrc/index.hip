@@ -242,8 +242,8 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
                 return rc;
             }
             layout_ = layout;
-        } else if (layout == 4 || layout == 5) {
-            rc = build_fat(tbl_, hc, steps, layout == 5, tblf_, buff_, err, [this] { release_one_step(); }, &fat_failed_level_);
+        } else if (layout >= 4 && layout <= 6) {
+            rc = build_fat(tbl_, hc, steps, layout - 4, tblf_, buff_, err, [this] { release_one_step(); }, &fat_failed_level_);
             if (rc != COLBWT_OK) {
                 release();
                 return rc;

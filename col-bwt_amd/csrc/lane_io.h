@@ -297,8 +297,9 @@ struct OutAccPml {
     uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = 0, r13 = 0, r14 = 0, r15 = 0, r16 = 0, r17 = 0, r18 = 0, r19 = 0;
     uint32_t cnt = 0;
 
-    // n <= 8 elements: values l_new - e for element e (keep = 0: n <= 2 elements, all of them 0)
-    __device__ __forceinline__ void push_run(uint32_t n, uint32_t l_new, uint32_t keep = 0xFFFFFFFFu) {
+    // n <= 8 elements: values l_new - e for element e; keep / keep1 = 0 clear elements 0-1 / 2-3 instead
+    // (what a mismatch entry reports: (0, 0), or (1, 0, 0) = push_run(3, 1, ~0u, 0))
+    __device__ __forceinline__ void push_run(uint32_t n, uint32_t l_new, uint32_t keep = 0xFFFFFFFFu, uint32_t keep1 = 0xFFFFFFFFu) {
         // up by n halfwords = (n >> 1) dwords, then 16 bits
         const bool d4 = n & 8u, d2 = n & 4u, d1 = n & 2u;
         r19 = d4 ? r15 : r19;
@@ -382,9 +383,9 @@ struct OutAccPml {
         r2 = __builtin_amdgcn_perm(r2, r1, sel16);
         r1 = __builtin_amdgcn_perm(r1, r0, sel16);
         r0 = __builtin_amdgcn_perm(r0, 0u, sel16);
-        const uint32_t base = ((l_new & 0xFFFFu) | ((l_new - 1u) << 16)) & keep;   // elements 0 and 1
-        r0 |= (base - 0u * 0x00020002u) & (n >= 2u ? 0xFFFFFFFFu : (n == 1u ? 0x0000FFFFu : 0u));
-        r1 |= (base - 1u * 0x00020002u) & (n >= 4u ? 0xFFFFFFFFu : (n == 3u ? 0x0000FFFFu : 0u));
+        const uint32_t base = (l_new & 0xFFFFu) | ((l_new - 1u) << 16);   // elements 0 and 1
+        r0 |= (base - 0u * 0x00020002u) & (n >= 2u ? 0xFFFFFFFFu : (n == 1u ? 0x0000FFFFu : 0u)) & keep;
+        r1 |= (base - 1u * 0x00020002u) & (n >= 4u ? 0xFFFFFFFFu : (n == 3u ? 0x0000FFFFu : 0u)) & keep1;
         r2 |= (base - 2u * 0x00020002u) & (n >= 6u ? 0xFFFFFFFFu : (n == 5u ? 0x0000FFFFu : 0u));
         r3 |= (base - 3u * 0x00020002u) & (n >= 8u ? 0xFFFFFFFFu : (n == 7u ? 0x0000FFFFu : 0u));
         cnt += n;

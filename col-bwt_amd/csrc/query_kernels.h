@@ -84,14 +84,14 @@ struct FatBuffers {
     uint64_t bytes() const;
     void release();
 };
-// Line rows with `steps` own steps (fat_build.hip), with in-row mismatch slots or with mismatch
-// lines (fat_layout.h); same contract as build_sk.
+// Line rows with `steps` own steps (fat_build.hip), with in-row mismatch slots (mismatch_lines = 0),
+// with mismatch lines (1) or with deep ones (2: fat_layout.h); same contract as build_sk.
 // fat_steps_supported: the step counts compiled in.  On failure *failed_level (nullable) says how
 // far the build got: the refinement level (2 .. steps) that could not be built -- a build with
 // at least that many steps fails the same way -- or steps + 1 when the levels fit and the final
 // tables did not.
 bool fat_steps_supported(int steps);
-int build_fat(const DevTable &T, const HintChars &chars, int steps, bool mismatch_lines, FatTable &out, FatBuffers &buf,
+int build_fat(const DevTable &T, const HintChars &chars, int steps, int mismatch_lines, FatTable &out, FatBuffers &buf,
               std::string &err, const std::function<void()> &source_done, int *failed_level);
 // The query over line rows (fat_query.hip).
 void launch_fat_query(const FatTable &T, const uint8_t *d_bases, const uint64_t *d_read_off, uint64_t n_reads, uint64_t n_bases,

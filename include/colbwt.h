@@ -59,7 +59,7 @@ typedef struct colbwt_info {
     uint32_t sigma;        /* distinct characters present in the table */
     uint32_t device;       /* HIP device ordinal                       */
     uint64_t device_bytes; /* HBM held by the index                    */
-    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS / _MISMATCH_LINES */
+    uint32_t layout;       /* COLBWT_LAYOUT_ONE_STEP / _TWO_ / _THREE_ / _LINE_ROWS / _MISMATCH_LINES[_DEEP] */
     uint32_t layout_shape; /* line rows: own steps << 8 | steps per mismatch slot; else 0 */
     uint64_t table_rows;   /* rows of the HBM table actually queried   */
     uint32_t n_devices;    /* replicas of the table (colbwt_index_open_devices); the fields above describe the first */
@@ -115,6 +115,12 @@ int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colb
  * row of the file. */
 #define COLBWT_LAYOUT_MISMATCH_LINES 5
 #define COLBWT_LAYOUT_MISMATCH_LINES_STEPS(K) (COLBWT_LAYOUT_MISMATCH_LINES | ((K) << 8))
+/* MISMATCH_LINES_DEEP: the same with 128-byte entries that also resolve the base after those two when
+ * it matches -- between two mismatches of a stretch there is often exactly one matching base, and
+ * with it resolved in the entry the lane goes from entry to entry.  MISMATCH_LINES + ~190 bytes per
+ * row of the file; what AUTO tries first. */
+#define COLBWT_LAYOUT_MISMATCH_LINES_DEEP 6
+#define COLBWT_LAYOUT_MISMATCH_LINES_DEEP_STEPS(K) (COLBWT_LAYOUT_MISMATCH_LINES_DEEP | ((K) << 8))
 int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
                              colbwt_index **out);
 int colbwt_index_open_memory_layout(const void *col_pml_bytes, uint64_t len, const colbwt_widths *widths,

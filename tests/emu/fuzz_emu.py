@@ -42,7 +42,7 @@ def one(seed):
     bases, off = helpers.concat_reads(reads)
     ep, ec = oracle.OracleIndex(img).query_batch(bases, off)
     # line rows (4) and line rows with mismatch lines (5), at varying depths
-    fat = {0: (4, 5 | (4 << 8)), 1: (4 | (6 << 8), 5), 2: (5 | ((4 + seed // 3 % 5) << 8),)}[seed % 3]
+    fat = {0: (4, 5 | (4 << 8), 6), 1: (4 | (6 << 8), 5, 6 | (5 << 8)), 2: (5 | ((4 + seed // 3 % 5) << 8), 6 | ((4 + seed // 3 % 5) << 8))}[seed % 3]
     for layout in (1, 2, 3) + fat:
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         p, c, _ = tbl.query_batch(bases, off)

@@ -32,9 +32,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 LINE_ROWS = 4                     # include/colbwt.h COLBWT_LAYOUT_LINE_ROWS (| steps << 8)
 MIS_LINES = 5                     # COLBWT_LAYOUT_MISMATCH_LINES (| steps << 8)
+MIS_DEEP = 6                      # COLBWT_LAYOUT_MISMATCH_LINES_DEEP (| steps << 8)
 
 
-def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS, MIS_LINES)):
+def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP)):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
@@ -196,7 +197,7 @@ def main():
         reads = helpers.backward_walk_reads(img, 40, 70, 0.02, seed=seed)
         reads += rand_reads(rng, 40, 0, 90)
         reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
-        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS, MIS_LINES | (6 << 8)), 257: (LINE_ROWS | (5 << 8), MIS_LINES | (4 << 8))}.get(rows, ()))
+        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS, MIS_LINES | (6 << 8), MIS_DEEP | (7 << 8)), 257: (LINE_ROWS | (5 << 8), MIS_LINES | (4 << 8), MIS_DEEP | (4 << 8))}.get(rows, (MIS_DEEP,)))
     img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=8, thr_mode=1)   # thresholds inside rows: cut out
     check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs")
 
@@ -218,7 +219,7 @@ def main():
     for label, alpha in (("hints_sigma4", b"ACGT"), ("hints_sigma5", b"\x01ACGT"), ("nohints_sigma7", b"\x01ACGNTac")):
         img = helpers.random_table(rng, 1500, alphabet=alpha)
         check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label,
-              extra_layouts=(LINE_ROWS, MIS_LINES) if label == "nohints_sigma7" else (MIS_LINES | (5 << 8),))
+              extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP) if label == "nohints_sigma7" else (MIS_LINES | (5 << 8), MIS_DEEP | (6 << 8)))
 
     # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
     r = 600
@@ -283,14 +284,14 @@ def main():
     bases, off = helpers.concat_reads(reads)
     epml, ecid = oracle.OracleIndex(bytes(img)).query_batch(bases, off)
     full = {}
-    for layout in (1, 2, 3, 4, 5):
+    for layout in (1, 2, 3, 4, 5, 6):
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         full[layout] = tbl.info().device_bytes
         tbl.close()
-    assert full[1] < full[2] < full[3] < full[4] < full[5]
+    assert full[1] < full[2] < full[3] < full[4] < full[5] < full[6]
     del os.environ["COLBWT_LAYOUT"]                   # the engine's own choice from here on
-    # the ladder (capi.hip): mismatch lines, line rows at K = 8 / 6 / 4, three-, two-, one-step rows
-    for budget_mb, expect in ((10_000, (5,)), (full[5] / 2**20 - 0.01, (4,)), (full[4] / 2**20 - 0.01, (4, 3)),
+    # the ladder (capi.hip): deep mismatch lines, mismatch lines, line rows at K = 8 / 6 / 4, three-, two-, one-step rows
+    for budget_mb, expect in ((10_000, (6,)), (full[6] / 2**20 - 0.01, (5, 4)), (full[5] / 2**20 - 0.01, (4,)), (full[4] / 2**20 - 0.01, (4, 3)),
                               (full[3] / 2**20 - 0.01, (2,)), (full[2] / 2**20 - 0.01, (1,))):
         os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)
         tbl = pkg.ColPml.from_bytes(img, layout=0)

@@ -20,8 +20,8 @@ pytestmark = pytest.mark.gpu
 
 # HBM layouts every parity case runs on (include/colbwt.h): 1 = one-step, 2 / 3 = K-step rows,
 # 4 = line rows with the default number of look-ahead steps and with two more (steps << 8),
-# 5 = line rows with mismatch lines, likewise
-LAYOUTS = (1, 2, 3, 4, 4 | (5 << 8), 4 | (4 << 8), 5, 5 | (6 << 8), 5 | (4 << 8))
+# 5 / 6 = line rows with mismatch lines / deep mismatch lines, likewise
+LAYOUTS = (1, 2, 3, 4, 4 | (5 << 8), 4 | (4 << 8), 5, 5 | (4 << 8), 6, 6 | (6 << 8), 6 | (4 << 8))
 
 
 def _loaded_hip_lib(pkg):
@@ -258,7 +258,7 @@ def test_device_resident_entry_point_and_read_sampler(pkg, oracle):
     assert 0.02 < resets < 0.6          # the recipe's mix of extends and resets
 
 
-@pytest.mark.parametrize("layout", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("layout", [1, 2, 3, 4, 5, 6])
 def test_full_scale_properties(pkg, oracle, layout, c2_image):
     """BASELINE config C2 scale (2e8 rows): size-independent properties --
     idempotence (two runs, identical bytes), batch-position independence (a
@@ -385,7 +385,7 @@ def test_concurrent_host_threads_share_one_index(pkg, oracle):
         assert np.array_equal(results[t][0], ep) and np.array_equal(results[t][1], ec)
 
 
-@pytest.mark.parametrize("layout", [4, 5])
+@pytest.mark.parametrize("layout", [4, 6])
 def test_many_overlapping_launches_on_one_index(pkg, oracle, layout):
     """include/colbwt.h: any number of colbwt_query_device launches may be in flight on one index.
     48 asynchronous launches on 24 streams (two per stream, nothing waited for in between) against
@@ -428,7 +428,7 @@ def test_open_close_does_not_leak_hbm(pkg):
     image = pkg.synth_index(1_000_000, mean_len=8, split_permille=0, seed=5)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info(0)[0]
-    for layout in (1, 2, 3, 4, 5, 0) * 2:
+    for layout in (1, 2, 3, 4, 5, 6, 0) * 2:
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
         assert tbl.info().device_bytes > 0
         tbl.close()

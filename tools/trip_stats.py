@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub-permille", type=int, default=10)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--layout", type=int, default=4, help="4 = line rows, 5 = line rows with mismatch lines")
+    ap.add_argument("--layout", type=int, default=4, help="4 = line rows, 5 / 6 = line rows with (deep) mismatch lines")
     a = ap.parse_args()
     import torch
     pkg = load_package()
@@ -38,12 +38,12 @@ def main():
     d_cid = torch.zeros(n * m + 16, dtype=torch.uint8, device=dev)
     L = pkg.lib()
     out = (C.c_ulonglong * 16)()
-    stats_fn = L.colbwt_debug_fat2_stats if a.layout == 5 else L.colbwt_debug_fat_stats
+    stats_fn = L.colbwt_debug_fat2_stats if a.layout in (5, 6) else L.colbwt_debug_fat_stats
     stats_fn(out, 1)
     st = tbl.query_device(d_bases.data_ptr(), d_off.data_ptr(), n, n * m, d_pml.data_ptr(), d_cid.data_ptr(), timed=True)
     torch.cuda.synchronize()
     stats_fn(out, 1)
-    if a.layout == 5:
+    if a.layout in (5, 6):
         names = ["row_trips", "fast_forward", "entry_trips", "scan", "absent", "idle", "row_to_entry", "unused"]
     else:
         names = ["live", "fast_forward", "slot", "scan", "absent", "idle", "chunk_ends", "skip_arrivals"]
@@ -51,7 +51,7 @@ def main():
     wave_trips = max(int(out[8]), 1)
     clocks = {"wave_trips": wave_trips, "boundary": out[12] / wave_trips, "rows_issue": out[13] / wave_trips,
               "flush": out[14] / wave_trips, "other_requests": out[9] / wave_trips, "wait": out[10] / wave_trips,
-              "compute": out[11] / wave_trips} if a.layout != 5 else {}
+              "compute": out[11] / wave_trips} if a.layout not in (5, 6) else {}
     d.update(kernel_ms=st.kernel_ms, per_read={k: round(v / n, 3) for k, v in d.items()}, rows=int(tbl.info().table_rows),
              steps=a.steps, layout=a.layout, clocks=clocks, resets=float((d_pml[:n * m] == 0).float().mean().item()))
     print(json.dumps(d))
