@@ -30,7 +30,7 @@
 
 using namespace colbwt;
 
-#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_MISMATCH_LINES_DEEP
+#define COLBWT_LAYOUT_DEFAULT_CHOICE COLBWT_LAYOUT_MISMATCH_LINES
 constexpr int kDefaultLineSteps = 8;
 
 // Device buffers, stream and events of one host-entry query, kept with the handle between calls
@@ -567,7 +567,7 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
         // pass, before anything of it was allocated): candidates that have to pass the same level
         // are not tried at all, so an index far too large for line rows costs one counting pass.
         struct Candidate { int layout, steps; };
-        static const Candidate ladder[] = {{COLBWT_LAYOUT_MISMATCH_LINES_DEEP, 8}, {COLBWT_LAYOUT_MISMATCH_LINES, 8},
+        static const Candidate ladder[] = {{COLBWT_LAYOUT_MISMATCH_LINES_DEEP, 8}, {COLBWT_LAYOUT_MISMATCH_LINES, 8},   // (deep: only when asked for)
                                            {COLBWT_LAYOUT_LINE_ROWS, 8}, {COLBWT_LAYOUT_LINE_ROWS, 6},
                                            {COLBWT_LAYOUT_LINE_ROWS, 4},      {COLBWT_LAYOUT_THREE_STEP, 0}, {COLBWT_LAYOUT_TWO_STEP, 0},
                                            {COLBWT_LAYOUT_ONE_STEP, 0}};
