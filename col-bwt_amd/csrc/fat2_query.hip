@@ -29,6 +29,7 @@
 #include "fat_cursor.h"
 #include "fat_layout.h"
 #include "lane_io.h"
+#include "lane_out.h"
 #include "query_kernels.h"
 
 namespace colbwt {
@@ -75,8 +76,8 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
     rc.commit();
     done = !rc.enter_chunk(plan, claim);
 
-    OutAccPml acc_pml;
-    OutAccCid acc_cid;
+    OutRuns acc;                                    // what the lane has reported and not yet stored (lane_out.h)
+    uint32_t trip = 0;                              // the wave flushes every OutRuns::kPeriod-th trip
     LaneWindow win;
     win.init(rc.off + rc.k - 1);
     uint4 (*const my_win)[64] = s_win[wave];
@@ -93,18 +94,17 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
     unsigned long long stat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     while (__any(!done)) {
-        // ---- (1) where the lane stands (registers and LDS only, fat_query.hip)
-        bool chunk_end = false, step_back = false;
-        uint64_t end_gl = 0;
+        // ---- (1) where the lane stands (registers and LDS only, fat_query.hip).  A lane whose chunk is
+        // reported enters its next one only once the wave's flush has taken what it still holds: the
+        // collector describes ONE stretch of addresses (1.5 idle trips on average, once per chunk).
+        bool step_back = false;
         if (!done && rc.k == 0 && !rc.next_in_flight && (rc.r != rc.r_lo || rc.nc_ready)) {
             if (rc.r != rc.r_lo) {
                 rc.r -= 1;
                 rc.k = rc.off - rc.next_off;
                 rc.off = rc.next_off;
                 step_back = rc.r > rc.r_lo;
-            } else {
-                chunk_end = true;
-                end_gl = rc.off;
+            } else if (kWide || acc.cnt == 0) {
                 done = !rc.enter_chunk(plan, claim);
                 if (!done) win.init(rc.off + rc.k - 1);
             }
@@ -130,14 +130,6 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                                                  16, 0, 0);
         }
         // ---- (3) the trip's other memory traffic, behind the lines
-        if constexpr (!kWide) {
-            if (chunk_end) {
-                acc_pml.flush_group((uint16_t *)pml, end_gl);
-                acc_pml.flush_rest((uint16_t *)pml, end_gl);
-                acc_cid.flush_group(cid, end_gl);
-                acc_cid.flush_rest(cid, end_gl);
-            }
-        }
         if (live && win.avail(g) < (k < 8u ? (uint32_t)k : 8u)) win.request(my_win, bases, g);
         if (step_back) { rc.in_next = read_off[rc.r - 1]; rc.next_in_flight = true; }
         if (!done && rc.fetch_pending) rc.request_chunk(plan, read_off);
@@ -332,17 +324,19 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                     cid[g - consumed + 1 + e] = (uint8_t)(ids >> (8 * e));
                 }
             } else {
-                acc_pml.push_run(consumed, l_new, keep, keep1);
-                acc_cid.push_run(consumed, (uint32_t)ids, (uint32_t)(ids >> 32));
+                acc.push_run(consumed, l_new, keep, keep1, (uint32_t)ids, (uint32_t)(ids >> 32));
             }
             k -= consumed;
         }
-        // ---- (5) the output groups the trip completed, all lanes' at once
+        // ---- (5) every fourth trip: what the lanes hold from a block boundary up, and all of what the
+        // lanes hold whose chunk is reported, leaves -- the staged lines are read, their LDS is the
+        // flush's working area
         wave_sync();
         if constexpr (!kWide) {
-            acc_pml.flush_group_wave((uint16_t *)pml, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
-            acc_cid.flush_group_wave(cid, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
+            if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1)
+                acc.flush_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, &s_stage[wave][0][0], lane);
         }
+        ++trip;
         wave_sync();   // the next trip overwrites s_jx and the staged lines
     }
 #ifdef COLBWT_COUNT_TRIPS
