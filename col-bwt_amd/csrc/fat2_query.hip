@@ -333,8 +333,12 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
         // flush's working area
         wave_sync();
         if constexpr (!kWide) {
+#ifdef COLBWT_ABL_NO_FLUSH         // timing experiments only
+            if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1) acc.cnt = acc.cnt > 90 ? 1 : 0;
+#else
             if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1)
                 acc.flush_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, &s_stage[wave][0][0], lane);
+#endif
         }
         ++trip;
         wave_sync();   // the next trip overwrites s_jx and the staged lines

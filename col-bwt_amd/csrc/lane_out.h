@@ -31,14 +31,21 @@
 
 #include "lane_io.h"
 
+// timing experiments only (tools/ab_parts.sh): -DCOLBWT_ABL_NO_STORES keeps the flush and drops its stores
+#ifdef COLBWT_ABL_NO_STORES
+#define COLBWT_ABL_IF if (ltop == 0xFFFFFFF1u)
+#else
+#define COLBWT_ABL_IF
+#endif
+
 namespace colbwt {
 
 struct OutRuns {
     static constexpr uint32_t kBlock = 64;            // elements per block
     static constexpr uint32_t kPeriod = 4;            // trips between flushes
     static constexpr uint32_t kSlots = 32;            // lanes whose registers one pass of the flush parks
-    // LDS of a flush pass (uint4 units): kSlots x 8 (the dumped registers), then 64 items x 2
-    static constexpr uint32_t kItemBase = kSlots * 8, kLdsQ = kItemBase + 64 * 2;
+    // LDS of a flush pass (uint4 units): kSlots x 6 (the dumped col-id registers), then 64 items x 4
+    static constexpr uint32_t kSlotQ = 6, kItemQ = 4, kItemBase = kSlots * kSlotQ, kLdsQ = kItemBase + 64 * kItemQ;
 
     uint32_t z0a = 0, z0b = 0, z0c = 0, z1a = 0, z1b = 0, z1c = 0;   // bit e: element e restarts at 0 / at 1
     uint32_t ltop = 0;                                               // value of the element above the collector's highest
@@ -170,6 +177,47 @@ struct OutRuns {
         return value_at(zz, zh, yy, yh, ltop, cnt - e);
     }
 
+    // The low 64 bits of a 96-bit mask shifted down by s < 96
+    static __device__ __forceinline__ uint64_t low64_from(uint32_t a, uint32_t b, uint32_t c, uint32_t s) {
+        uint64_t lo = ((uint64_t)b << 32) | a;
+        uint32_t hi = c;
+        shr96(lo, hi, s);
+        return lo;
+    }
+    // Parks one item -- `count` <= 64 elements from collector element e_lo on, going to global element
+    // address `addr` (all inside one 64-element block), `lt` = the value of the element above its top
+    // one -- for the lanes that will store it: a header and, per 8-element piece p of the block, one
+    // dword { value above the piece's highest element of the item, its restart-at-0 bits, its
+    // restart-at-1 bits }: whoever stores a piece makes its values with 8-bit arithmetic alone.
+    __device__ __forceinline__ void park_item(uint4 *item, uint32_t slot, uint32_t e_lo, uint32_t count, uint64_t addr, uint32_t lt) const {
+        const uint32_t o_lo = (uint32_t)addr & (kBlock - 1), o_hi = o_lo + count;
+        const uint64_t in_item = count >= 64 ? ~0ull : (1ull << count) - 1ull;
+        const uint64_t Z0 = (low64_from(z0a, z0b, z0c, e_lo) & in_item) << o_lo;      // block-aligned restart masks of the item
+        const uint64_t Z1 = (low64_from(z1a, z1b, z1c, e_lo) & in_item) << o_lo;
+        const uint32_t z0w[2] = {(uint32_t)Z0, (uint32_t)(Z0 >> 32)}, z1w[2] = {(uint32_t)Z1, (uint32_t)(Z1 >> 32)};
+        uint32_t pm[8];
+        uint32_t v = lt;
+#pragma unroll
+        for (int p = 7; p >= 0; --p) {
+            const uint32_t b0 = (z0w[p >> 2] >> (8 * (p & 3))) & 0xFFu, b1 = (z1w[p >> 2] >> (8 * (p & 3))) & 0xFFu;
+            pm[p] = (v & 0xFFFFu) | (b0 << 16) | (b1 << 24);
+            const uint32_t lo_p = o_lo > 8u * p ? o_lo : 8u * p, hi_p = o_hi < 8u * p + 8u ? o_hi : 8u * p + 8u;
+            if (hi_p > lo_p) {                                       // the value of the piece's lowest element of the item
+                const uint32_t bits = b0 | b1;
+                if (bits) {
+                    const uint32_t q = (uint32_t)__builtin_ctz(bits);
+                    v = q - (lo_p - 8u * p) + ((b1 >> q) & 1u);
+                } else {
+                    v += hi_p - lo_p;
+                }
+            }
+        }
+        item[0] = make_uint4(slot, e_lo, count, (uint32_t)addr);
+        item[1] = make_uint4((uint32_t)(addr >> 32), 0u, 0u, 0u);
+        item[2] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        item[3] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
+    }
+
     // The flush of a whole wave (every lane calls it).  gl: global index of this lane's element 0;
     // active: the lane has a chunk; final: its chunk is reported, everything leaves.  lds: kLdsQ uint4
     // of the wave's own (the staged lines: they are read by now).
@@ -182,6 +230,7 @@ struct OutRuns {
         const unsigned long long emit = __ballot(has_a || has_b);
         if (emit == 0) return;
         const uint32_t n_a = has_a ? cnt - below : 0u;
+        const uint32_t v_cut = has_a ? value(below) : ltop;          // the value just above what stays / above item B
         const unsigned long long lt = (1ull << lane) - 1ull;
         const uint32_t rank = (uint32_t)__builtin_popcountll(emit & lt), lanes = (uint32_t)__builtin_popcountll(emit);
         for (uint32_t first = 0; first < lanes; first += kSlots) {
@@ -192,106 +241,100 @@ struct OutRuns {
             const uint32_t n_ra = (uint32_t)__builtin_popcountll(m_ra), n_rb = (uint32_t)__builtin_popcountll(m_rb);
             const uint32_t n_rag = n_ra + n_rb, n_items = n_rag + (uint32_t)__builtin_popcountll(m_fa);
             if (mine) {
-                uint4 *slot = lds + 8 * (rank - first);
-        slot[0] = make_uint4(c0, c1, c2, c3);
-        slot[1] = make_uint4(c4, c5, c6, c7);
-        slot[2] = make_uint4(c8, c9, c10, c11);
-        slot[3] = make_uint4(c12, c13, c14, c15);
-        slot[4] = make_uint4(c16, c17, c18, c19);
-        slot[5] = make_uint4(c20, c21, c22, c23);
-                slot[6] = make_uint4(z0a, z0b, z0c, z1a);
-                slot[7] = make_uint4(z1b, z1c, ltop, cnt);
-                if (has_a) {
-                    const uint32_t at = rag_a ? (uint32_t)__builtin_popcountll(m_ra & lt) : n_rag + (uint32_t)__builtin_popcountll(m_fa & lt);
-                    const uint64_t a = gl + below;
-                    lds[kItemBase + 2 * at] = make_uint4(rank - first, below, n_a, (uint32_t)a);
-                    lds[kItemBase + 2 * at + 1] = make_uint4((uint32_t)(a >> 32), 0u, 0u, 0u);
-                }
-                if (has_b) {
-                    const uint32_t at = n_ra + (uint32_t)__builtin_popcountll(m_rb & lt);
-                    lds[kItemBase + 2 * at] = make_uint4(rank - first, 0u, rest, (uint32_t)gl);
-                    lds[kItemBase + 2 * at + 1] = make_uint4((uint32_t)(gl >> 32), 0u, 0u, 0u);
+                uint4 *slot = lds + kSlotQ * (rank - first);
+                slot[0] = make_uint4(c0, c1, c2, c3);
+                slot[1] = make_uint4(c4, c5, c6, c7);
+                slot[2] = make_uint4(c8, c9, c10, c11);
+                slot[3] = make_uint4(c12, c13, c14, c15);
+                slot[4] = make_uint4(c16, c17, c18, c19);
+                slot[5] = make_uint4(c20, c21, c22, c23);
+            }
+            // (one copy of park_item's code for both kinds of item: inlined twice it costs 50 registers)
+#pragma unroll 1
+            for (uint32_t which = 0; which < 2; ++which) {
+                const bool b_item = which != 0;
+                if (!__any(mine && (b_item ? has_b : has_a))) continue;
+                if (mine && (b_item ? has_b : has_a)) {
+                    const uint32_t at = b_item ? n_ra + (uint32_t)__builtin_popcountll(m_rb & lt)
+                                               : (rag_a ? (uint32_t)__builtin_popcountll(m_ra & lt) : n_rag + (uint32_t)__builtin_popcountll(m_fa & lt));
+                    park_item(lds + kItemBase + kItemQ * at, rank - first, b_item ? 0u : below, b_item ? rest : n_a,
+                              b_item ? gl : gl + below, b_item ? v_cut : ltop);
                 }
             }
             wave_sync();
-            // ---- whole 16-byte pieces: 8 of PML and 4 of col ids per item (PML tasks first, so that the
-            // lanes of an iteration mostly do the same thing); ONE store instruction per iteration
-            const uint32_t t_pml = 8u * n_items, t_all = 12u * n_items;
-            for (uint32_t t = lane; t < t_all; t += 64) {
-                const bool is_pml = t < t_pml;
-                const uint32_t it = is_pml ? t >> 3 : (t - t_pml) >> 2, piece = is_pml ? t & 7u : (t - t_pml) & 3u;
-                const uint4 h = lds[kItemBase + 2 * it];
-                const uint64_t addr = (uint64_t)h.w | ((uint64_t)lds[kItemBase + 2 * it + 1].x << 32), end = addr + h.z;
-                const uint32_t per = is_pml ? 8u : 16u;
-                const uint64_t w0 = (addr & ~(uint64_t)(kBlock - 1)) + (uint64_t)piece * per;   // the piece's first element (global)
-                if (w0 < addr || w0 + per > end) continue;                                   // not wholly inside the item
-                const uint32_t e = h.y + (uint32_t)(w0 - addr);                             // its first element in the collector
-                const uint4 *slot = lds + 8 * h.x;
-                uint8_t *dst;
-                uint4 val;
-                if (is_pml) {
-                    const uint4 ma = slot[6], mb = slot[7];
-                    uint64_t zz = ((uint64_t)(ma.y | mb.x) << 32) | (ma.x | ma.w), yy = ((uint64_t)mb.x << 32) | ma.w;
-                    uint32_t zh = ma.z | mb.y, yh = mb.y;
-                    shr96(zz, zh, e);
-                    shr96(yy, yh, e);
-                    // element e + 7 first, then down: a restart says its value, else one more than the element above
-                    uint64_t z7 = zz, y7 = yy;
-                    uint32_t z7h = zh, y7h = yh;
-                    shr96(z7, z7h, 7);
-                    shr96(y7, y7h, 7);
-                    uint32_t v = value_at(z7, z7h, y7, y7h, mb.z, mb.w - e - 7);
-                    const uint32_t z1m = (uint32_t)yy, z0m = (uint32_t)zz & ~z1m;            // restarts at 1 / at 0 among the piece's 8
-                    uint32_t out[4] = {0, 0, 0, 0};
+            // ---- whole 16-byte pieces of PML: 8 per item, one store instruction per 64 of them
+            for (uint32_t t = lane; t < 8u * n_items; t += 64) {
+                const uint32_t it = t >> 3, piece = t & 7u;
+                const uint4 *item = lds + kItemBase + kItemQ * it;
+                const uint4 h = item[0];
+                const uint64_t addr = (uint64_t)h.w | ((uint64_t)item[1].x << 32), end = addr + h.z;
+                const uint64_t w0 = (addr & ~(uint64_t)(kBlock - 1)) + 8u * piece;            // the piece's first element (global)
+                if (w0 < addr || w0 + 8u > end) continue;                                    // not wholly inside the item
+                const uint32_t d = reinterpret_cast<const uint32_t *>(item + 2)[piece];
+                const uint32_t b0 = (d >> 16) & 0xFFu, b1 = d >> 24;
+                uint32_t v = d & 0xFFFFu;                                                    // the value above the piece
+                uint32_t out[4] = {0, 0, 0, 0};
 #pragma unroll
-                    for (int i = 7; i >= 0; --i) {
-                        if (i != 7) v = (z1m >> i) & 1u ? 1u : ((z0m >> i) & 1u ? 0u : v + 1u);
-                        out[i >> 1] |= (v & 0xFFFFu) << (16 * (i & 1));
-                    }
-                    dst = reinterpret_cast<uint8_t *>(pml + w0);
-                    val = make_uint4(out[0], out[1], out[2], out[3]);
-                } else {
-                    const uint32_t *bytes = reinterpret_cast<const uint32_t *>(slot);
-                    const uint32_t d = e >> 2, sel = 0x03020100u + 0x01010101u * (e & 3u);
-                    const uint32_t x0 = bytes[d], x1 = bytes[d + 1], x2 = bytes[d + 2], x3 = bytes[d + 3], x4 = bytes[d + 4];
-                    dst = cid + w0;
-                    val = make_uint4(__builtin_amdgcn_perm(x1, x0, sel), __builtin_amdgcn_perm(x2, x1, sel),
-                                     __builtin_amdgcn_perm(x3, x2, sel), __builtin_amdgcn_perm(x4, x3, sel));
+                for (int i = 7; i >= 0; --i) {                       // a restart says its value, else one more than the element above
+                    v = (b1 >> i) & 1u ? 1u : ((b0 >> i) & 1u ? 0u : v + 1u);
+                    out[i >> 1] |= (v & 0xFFFFu) << (16 * (i & 1));
                 }
-                *reinterpret_cast<uint4 *>(dst) = val;
+                COLBWT_ABL_IF *reinterpret_cast<uint4 *>(pml + w0) = make_uint4(out[0], out[1], out[2], out[3]);
             }
-            // ---- the partial pieces of the ragged items, byte by byte: an item covers at most two pieces
-            // of an array partly, the one its first element is in and the one its end is in (16 bytes of
-            // PML = 8 elements, 16 bytes of col ids each): 64 byte tasks per item, one store instruction
-            // per 64 of them
-            for (uint32_t t = lane; t < 64u * n_rag; t += 64) {
-                const uint32_t it = t >> 6, q = t & 31u;
-                const bool tail = (t >> 5) & 1u, is_pml = q < 16u;
-                const uint4 h = lds[kItemBase + 2 * it];
-                const uint64_t addr = (uint64_t)h.w | ((uint64_t)lds[kItemBase + 2 * it + 1].x << 32), end = addr + h.z;
-                const uint64_t mask = is_pml ? 7u : 15u;
-                const uint64_t w_head = addr & ~mask, w_tail = end & ~mask;
-                if (tail ? ((end & mask) == 0 || (w_tail == w_head && (addr & mask) != 0)) : (addr & mask) == 0) continue;
-                const uint64_t el = (tail ? w_tail : w_head) + (is_pml ? q >> 1 : q - 16u);   // this byte's element (global)
+            // ---- whole 16-byte pieces of col ids: 4 per item, re-aligned from the dumped registers
+            for (uint32_t t = lane; t < 4u * n_items; t += 64) {
+                const uint32_t it = t >> 2, piece = t & 3u;
+                const uint4 *item = lds + kItemBase + kItemQ * it;
+                const uint4 h = item[0];
+                const uint64_t addr = (uint64_t)h.w | ((uint64_t)item[1].x << 32), end = addr + h.z;
+                const uint64_t w0 = (addr & ~(uint64_t)(kBlock - 1)) + 16u * piece;
+                if (w0 < addr || w0 + 16u > end) continue;
+                const uint32_t e = h.y + (uint32_t)(w0 - addr);                              // its first element in the collector
+                const uint32_t *bytes = reinterpret_cast<const uint32_t *>(lds + kSlotQ * h.x);
+                const uint32_t dq = e >> 2, sel = 0x03020100u + 0x01010101u * (e & 3u);
+                const uint32_t x0 = bytes[dq], x1 = bytes[dq + 1], x2 = bytes[dq + 2], x3 = bytes[dq + 3], x4 = bytes[dq + 4 < 24u ? dq + 4 : 23u];   // beyond the registers only when it is not used
+                COLBWT_ABL_IF *reinterpret_cast<uint4 *>(cid + w0) =
+                    make_uint4(__builtin_amdgcn_perm(x1, x0, sel), __builtin_amdgcn_perm(x2, x1, sel), __builtin_amdgcn_perm(x3, x2, sel),
+                               __builtin_amdgcn_perm(x4, x3, sel));
+            }
+            // ---- the partial pieces of the ragged items: an item covers at most two pieces of an array
+            // partly, the one its first element is in and the one its end is in.  PML: 2 x 8 elements,
+            // a halfword store each; col ids: 2 x 16 elements, a byte store each -- one store
+            // instruction per 64 elements.
+            for (uint32_t t = lane; t < 16u * n_rag; t += 64) {
+                const uint32_t it = t >> 4, i = t & 7u;
+                const bool tail = (t >> 3) & 1u;
+                const uint4 *item = lds + kItemBase + kItemQ * it;
+                const uint4 h = item[0];
+                const uint64_t addr = (uint64_t)h.w | ((uint64_t)item[1].x << 32), end = addr + h.z;
+                const uint64_t w_head = addr & ~7ull, w_tail = end & ~7ull;
+                if (tail ? ((end & 7u) == 0 || (w_tail == w_head && (addr & 7u) != 0)) : (addr & 7u) == 0) continue;
+                const uint64_t w0 = tail ? w_tail : w_head, el = w0 + i;
                 if (el < addr || el >= end) continue;
-                const uint32_t e = h.y + (uint32_t)(el - addr);
-                const uint4 *slot = lds + 8 * h.x;
-                uint8_t *dst;
-                uint32_t byte;
-                if (is_pml) {
-                    const uint4 ma = slot[6], mb = slot[7];
-                    uint64_t zz = ((uint64_t)(ma.y | mb.x) << 32) | (ma.x | ma.w), yy = ((uint64_t)mb.x << 32) | ma.w;
-                    uint32_t zh = ma.z | mb.y, yh = mb.y;
-                    shr96(zz, zh, e);
-                    shr96(yy, yh, e);
-                    const uint32_t v = value_at(zz, zh, yy, yh, mb.z, mb.w - e);
-                    dst = reinterpret_cast<uint8_t *>(pml + el) + (q & 1u);
-                    byte = v >> (8u * (q & 1u));
+                const uint32_t piece = (uint32_t)(w0 >> 3) & 7u;
+                const uint32_t d = reinterpret_cast<const uint32_t *>(item + 2)[piece];
+                const uint32_t b0 = (d >> 16) & 0xFFu, b1 = d >> 24, bits = (b0 | b1) >> i;   // restarts at or above this element (item's only)
+                const uint32_t hi = end - w0 < 8u ? (uint32_t)(end - w0) : 8u;                // the piece's elements of the item end here
+                uint32_t v;
+                if (bits) {
+                    const uint32_t q = (uint32_t)__builtin_ctz(bits);
+                    v = q + ((b1 >> (i + q)) & 1u);
                 } else {
-                    dst = cid + el;
-                    byte = reinterpret_cast<const uint8_t *>(slot)[e];
+                    v = (d & 0xFFFFu) + hi - i;
                 }
-                *dst = (uint8_t)byte;
+                COLBWT_ABL_IF pml[el] = (uint16_t)v;
+            }
+            for (uint32_t t = lane; t < 32u * n_rag; t += 64) {
+                const uint32_t it = t >> 5, i = t & 15u;
+                const bool tail = (t >> 4) & 1u;
+                const uint4 *item = lds + kItemBase + kItemQ * it;
+                const uint4 h = item[0];
+                const uint64_t addr = (uint64_t)h.w | ((uint64_t)item[1].x << 32), end = addr + h.z;
+                const uint64_t w_head = addr & ~15ull, w_tail = end & ~15ull;
+                if (tail ? ((end & 15u) == 0 || (w_tail == w_head && (addr & 15u) != 0)) : (addr & 15u) == 0) continue;
+                const uint64_t el = (tail ? w_tail : w_head) + i;
+                if (el < addr || el >= end) continue;
+                COLBWT_ABL_IF cid[el] = reinterpret_cast<const uint8_t *>(lds + kSlotQ * h.x)[h.y + (uint32_t)(el - addr)];
             }
             wave_sync();
         }
@@ -302,8 +345,8 @@ struct OutRuns {
                 ltop = 0;
                 cnt = 0;
             } else {
-                ltop = value(below);                                 // the lowest element that left
-                const uint64_t keep_lo = below >= 64 ? ~0ull : (1ull << below) - 1ull;   // below < 64
+                ltop = v_cut;                                        // the lowest element that left
+                const uint64_t keep_lo = (1ull << below) - 1ull;     // below < 64
                 z0a &= (uint32_t)keep_lo; z0b &= (uint32_t)(keep_lo >> 32); z0c = 0;
                 z1a &= (uint32_t)keep_lo; z1b &= (uint32_t)(keep_lo >> 32); z1c = 0;
                 cnt = below;
