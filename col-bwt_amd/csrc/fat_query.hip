@@ -32,6 +32,7 @@
 #include "fat_cursor.h"
 #include "fat_layout.h"
 #include "lane_io.h"
+#include "lane_out.h"
 #include "query_kernels.h"
 
 namespace colbwt {
@@ -67,8 +68,8 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
     rc.commit();
     done = !rc.enter_chunk(plan, claim);
 
-    OutAccPml acc_pml;
-    OutAccCid acc_cid;
+    OutRuns acc;                                    // what the lane has reported and not yet stored (lane_out.h)
+    uint32_t trip = 0;                              // the wave flushes every OutRuns::kPeriod-th trip
     LaneWindow win;
     win.init(rc.off + rc.k - 1);
     uint4 (*const my_win)[64] = s_win[wave];
@@ -89,20 +90,18 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
         // ---- (1) where the lane stands.  Registers and LDS only: nothing goes to global memory
         // before the rows are requested (a store or load issued here would have to be waited for
         // at the LDS hand-over below, a memory round trip ahead of the one that matters).
-        bool chunk_end = false, step_back = false;
-        uint64_t end_gl = 0;
+        bool step_back = false;
         if (!done && rc.k == 0 && !rc.next_in_flight && (rc.r != rc.r_lo || rc.nc_ready)) {
             // the read is reported (or empty): a new query starts at the read before it
-            // (col_bwt.hpp:503-508), or the chunk is finished
+            // (col_bwt.hpp:503-508), or the chunk is finished -- the lane enters its next one once the
+            // wave's flush has taken what it still holds (lane_out.h)
             if (rc.r != rc.r_lo) {
                 rc.r -= 1;
                 rc.k = rc.off - rc.next_off;
                 rc.off = rc.next_off;
                 step_back = rc.r > rc.r_lo;                  // the offset after this one is requested below
-            } else {
+            } else if (kWide || acc.cnt == 0) {
                 FAT_STAT(6);
-                chunk_end = true;                            // the collector is emptied below
-                end_gl = rc.off;
                 done = !rc.enter_chunk(plan, claim);
                 if (!done) win.init(rc.off + rc.k - 1);
             }
@@ -132,14 +131,6 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
         // ---- (3) the trip's other memory traffic, behind the rows: finished output groups, read
         // bytes for the lanes that run low (a trip looks at 8 bases), offsets for later boundaries.
         // All of it has landed at the one wait below.
-        if constexpr (!kWide) {
-            if (chunk_end) {                                 // what the finished chunk's last trips pushed
-                acc_pml.flush_group((uint16_t *)pml, end_gl);
-                acc_pml.flush_rest((uint16_t *)pml, end_gl);
-                acc_cid.flush_group(cid, end_gl);
-                acc_cid.flush_rest(cid, end_gl);
-            }
-        }
         FAT_CLOCK(6);
         if (live && win.avail(g) < (k < 8u ? (uint32_t)k : 8u)) win.request(my_win, bases, g);
         if (step_back) { rc.in_next = read_off[rc.r - 1]; rc.next_in_flight = true; }
@@ -238,8 +229,7 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
                             cid[g - consumed + 1 + e] = (uint8_t)(ids >> (8 * e));
                         }
                     } else {
-                        acc_pml.push_run(consumed, l_new);
-                        acc_cid.push_run(consumed, (uint32_t)ids, (uint32_t)(ids >> 32));
+                        acc.push_run(consumed, l_new, 0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)ids, (uint32_t)(ids >> 32));
                     }
                 }
                 k -= consumed;
@@ -273,9 +263,10 @@ void fat_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint6
         // their LDS serves as the parking area
         wave_sync();
         if constexpr (!kWide) {
-            acc_pml.flush_group_wave((uint16_t *)pml, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
-            acc_cid.flush_group_wave(cid, rc.off + rc.k, !done, &s_stage[wave][0][0], lane);
+            if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1)
+                acc.flush_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, &s_stage[wave][0][0], lane);
         }
+        ++trip;
         wave_sync();   // the next trip overwrites s_jx and the staged rows
         FAT_CLOCK(3);
 #ifdef COLBWT_COUNT_TRIPS

@@ -24,6 +24,7 @@
 #include "device_layout.h"
 #include "fat_cursor.h"
 #include "lane_io.h"
+#include "lane_out.h"
 #include "lf_device.h"
 #include "query_kernels.h"
 #include "sk_layout.h"
@@ -33,7 +34,7 @@ namespace colbwt {
 namespace {
 
 constexpr int K3 = 3;
-constexpr uint32_t kStagePieces = 288;          // per wave: 2 x 64 row pieces; the flush parks 64 groups x 4 pieces + 64 addresses here
+constexpr uint32_t kStagePieces = OutRuns::kLdsQ;   // per wave: 2 x 64 row pieces; then the working area of the wave's flush (lane_out.h)
 
 // col_pml::threshold_step (col_bwt.hpp:531-574) for a mismatch the row cannot turn into "the
 // target is d rows away": scans + (when the hint says so) the position compare.  Returns true
@@ -92,8 +93,8 @@ void sk3_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64
     rc.commit();
     done = !rc.enter_chunk(plan, claim);
 
-    OutAccPml acc_pml;
-    OutAccCid acc_cid;
+    OutRuns acc;                                      // what the lane has reported and not yet stored (lane_out.h)
+    uint32_t trip = 0;                                // the wave flushes every OutRuns::kPeriod-th trip
     LaneWindow win;
     win.init(rc.off + rc.k - 1);
     uint4 (*const my_win)[64] = s_win[wave];
@@ -106,17 +107,14 @@ void sk3_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64
 
     while (__any(!done)) {
         // ---- (1) where the lane stands (registers and LDS only; fat_query.hip)
-        bool chunk_end = false, step_back = false;
-        uint64_t end_gl = 0;
+        bool step_back = false;
         if (!done && rc.k == 0 && !rc.next_in_flight && (rc.r != rc.r_lo || rc.nc_ready)) {
             if (rc.r != rc.r_lo) {
                 rc.r -= 1;
                 rc.k = rc.off - rc.next_off;
                 rc.off = rc.next_off;
                 step_back = rc.r > rc.r_lo;
-            } else {
-                chunk_end = true;
-                end_gl = rc.off;
+            } else if (kWide || acc.cnt == 0) {              // the next chunk, once the wave's flush has taken what the lane holds
                 done = !rc.enter_chunk(plan, claim);
                 if (!done) win.init(rc.off + rc.k - 1);
             }
@@ -140,14 +138,6 @@ void sk3_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64
                 __builtin_amdgcn_global_load_lds(T.lines + (uint64_t)jq[q] * 32u + ((sub ^ q) << 4), &stage[q * 64], 16, 0, 0);
         }
         // ---- (3) the trip's other memory traffic, behind the rows
-        if constexpr (!kWide) {
-            if (chunk_end) {
-                acc_pml.flush_group((uint16_t *)pml, end_gl);
-                acc_pml.flush_rest((uint16_t *)pml, end_gl);
-                acc_cid.flush_group(cid, end_gl);
-                acc_cid.flush_rest(cid, end_gl);
-            }
-        }
         if (live && win.avail(g) < (k < 8u ? (uint32_t)k : 8u)) win.request(my_win, bases, g);
         if (step_back) { rc.in_next = read_off[rc.r - 1]; rc.next_in_flight = true; }
         if (!done && rc.fetch_pending) rc.request_chunk(plan, read_off);
@@ -251,17 +241,17 @@ void sk3_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64
                     cid[g - consumed + 1 + e] = (uint8_t)(ids >> (8 * e));
                 }
             } else {
-                acc_pml.push_run(consumed, l_new);
-                acc_cid.push_run(consumed, (uint32_t)ids, 0u);
+                acc.push_run(consumed, l_new, 0xFFFFFFFFu, 0xFFFFFFFFu, (uint32_t)ids, 0u);
             }
             k -= consumed;
         }
         // ---- (5) the output groups the trip completed, all lanes' at once
         wave_sync();
         if constexpr (!kWide) {
-            acc_pml.flush_group_wave((uint16_t *)pml, rc.off + rc.k, !done, stage, lane);
-            acc_cid.flush_group_wave(cid, rc.off + rc.k, !done, stage, lane);
+            if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1)
+                acc.flush_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, stage, lane);
         }
+        ++trip;
         wave_sync();   // the next trip overwrites s_jx and the staged rows
     }
 }
