@@ -43,9 +43,10 @@ namespace colbwt {
 struct OutRuns {
     static constexpr uint32_t kBlock = 64;            // elements per block
     static constexpr uint32_t kPeriod = 4;            // trips between flushes
-    static constexpr uint32_t kSlots = 32;            // lanes whose registers one pass of the flush parks
-    // LDS of a flush pass (uint4 units): kSlots x 6 (the dumped col-id registers), then 64 items x 4
-    static constexpr uint32_t kSlotQ = 6, kItemQ = 4, kItemBase = kSlots * kSlotQ, kLdsQ = kItemBase + 64 * kItemQ;
+    // LDS of a flush pass (uint4 units): kSlots x 6 (the dumped col-id registers of the lanes one pass
+    // parks), then 2 * kSlots items x 4 (a lane has at most two)
+    static constexpr uint32_t kSlotQ = 6, kItemQ = 4;
+    static constexpr uint32_t lds_q(uint32_t slots) { return slots * kSlotQ + 2 * slots * kItemQ; }
 
     uint32_t z0a = 0, z0b = 0, z0c = 0, z1a = 0, z1b = 0, z1c = 0;   // bit e: element e restarts at 0 / at 1
     uint32_t ltop = 0;                                               // value of the element above the collector's highest
@@ -219,10 +220,12 @@ struct OutRuns {
     }
 
     // The flush of a whole wave (every lane calls it).  gl: global index of this lane's element 0;
-    // active: the lane has a chunk; final: its chunk is reported, everything leaves.  lds: kLdsQ uint4
+    // active: the lane has a chunk; final: its chunk is reported, everything leaves.  lds: lds_q(kSlots) uint4
     // of the wave's own (the staged lines: they are read by now).
+    template <uint32_t kSlots = 32>
     __device__ __forceinline__ void flush_wave(uint16_t *pml, uint8_t *cid, uint64_t gl, bool active, bool final, uint4 *lds,
                                                uint32_t lane) {
+        constexpr uint32_t kItemBase = kSlots * kSlotQ;
         const uint32_t below = (0u - (uint32_t)gl) & (kBlock - 1);   // elements below the next block boundary
         const bool has_a = active && below < cnt;                    // from the boundary up: a block, or the chunk's ragged top
         const uint32_t rest = below < cnt ? below : cnt;

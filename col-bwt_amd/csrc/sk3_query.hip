@@ -34,7 +34,11 @@ namespace colbwt {
 namespace {
 
 constexpr int K3 = 3;
-constexpr uint32_t kStagePieces = OutRuns::kLdsQ;   // per wave: 2 x 64 row pieces; then the working area of the wave's flush (lane_out.h)
+// Lanes one pass of the wave's flush parks (lane_out.h).  16 (3.5 KB per wave) and a register cap of
+// 128 give FOUR workgroups per CU: measured slower, 23.5 against 22.3 ms on the 1e9-row index
+// (profiles/r03n_*) -- the kernel wants fewer passes per flush, not more waves.
+constexpr uint32_t kFlushSlots = 32;
+constexpr uint32_t kStagePieces = OutRuns::lds_q(kFlushSlots);   // per wave: 2 x 64 row pieces; then the flush's working area (7 KB)
 
 // col_pml::threshold_step (col_bwt.hpp:531-574) for a mismatch the row cannot turn into "the
 // target is d rows away": scans + (when the hint says so) the position compare.  Returns true
@@ -249,7 +253,7 @@ void sk3_query_kernel(SKTable T, const uint8_t *__restrict__ bases, const uint64
         wave_sync();
         if constexpr (!kWide) {
             if ((trip & (OutRuns::kPeriod - 1)) == OutRuns::kPeriod - 1)
-                acc.flush_wave((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, stage, lane);
+                acc.template flush_wave<kFlushSlots>((uint16_t *)pml, cid, rc.off + rc.k, !done, rc.k == 0 && rc.r == rc.r_lo, stage, lane);
         }
         ++trip;
         wave_sync();   // the next trip overwrites s_jx and the staged rows
