@@ -161,23 +161,6 @@ struct OutRuns {
             hi = s < 32 ? hi >> s : 0u;
         }
     }
-    // value of element e given the masks shifted down to e (zz = z0 | z1, yy = z1), the value above the
-    // collector and the elements from e to its top
-    static __device__ __forceinline__ uint32_t value_at(uint64_t zz_lo, uint32_t zz_hi, uint64_t yy_lo, uint32_t yy_hi, uint32_t ltop,
-                                                        uint32_t above) {
-        if (zz_lo == 0 && zz_hi == 0) return ltop + above;           // the run comes from above the collector
-        const uint32_t p = zz_lo ? (uint32_t)__builtin_ctzll(zz_lo) : 64u + (uint32_t)__builtin_ctz(zz_hi);
-        const uint32_t one = p < 64 ? (uint32_t)(yy_lo >> p) & 1u : (yy_hi >> (p - 64)) & 1u;
-        return p + one;
-    }
-    __device__ __forceinline__ uint32_t value(uint32_t e) const {   // e < cnt
-        uint64_t zz = ((uint64_t)(z0b | z1b) << 32) | (z0a | z1a), yy = ((uint64_t)z1b << 32) | z1a;
-        uint32_t zh = z0c | z1c, yh = z1c;
-        shr96(zz, zh, e);
-        shr96(yy, yh, e);
-        return value_at(zz, zh, yy, yh, ltop, cnt - e);
-    }
-
     // The low 64 bits of a 96-bit mask shifted down by s < 96
     static __device__ __forceinline__ uint64_t low64_from(uint32_t a, uint32_t b, uint32_t c, uint32_t s) {
         uint64_t lo = ((uint64_t)b << 32) | a;
@@ -190,7 +173,8 @@ struct OutRuns {
     // one -- for the lanes that will store it: a header and, per 8-element piece p of the block, one
     // dword { value above the piece's highest element of the item, its restart-at-0 bits, its
     // restart-at-1 bits }: whoever stores a piece makes its values with 8-bit arithmetic alone.
-    __device__ __forceinline__ void park_item(uint4 *item, uint32_t slot, uint32_t e_lo, uint32_t count, uint64_t addr, uint32_t lt) const {
+    // Returns the value of the item's lowest element.
+    __device__ __forceinline__ uint32_t park_item(uint4 *item, uint32_t slot, uint32_t e_lo, uint32_t count, uint64_t addr, uint32_t lt) const {
         const uint32_t o_lo = (uint32_t)addr & (kBlock - 1), o_hi = o_lo + count;
         const uint64_t in_item = count >= 64 ? ~0ull : (1ull << count) - 1ull;
         const uint64_t Z0 = (low64_from(z0a, z0b, z0c, e_lo) & in_item) << o_lo;      // block-aligned restart masks of the item
@@ -217,6 +201,7 @@ struct OutRuns {
         item[1] = make_uint4((uint32_t)(addr >> 32), 0u, 0u, 0u);
         item[2] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         item[3] = make_uint4(pm[4], pm[5], pm[6], pm[7]);
+        return v;
     }
 
     // The flush of a whole wave (every lane calls it).  gl: global index of this lane's element 0;
@@ -233,7 +218,7 @@ struct OutRuns {
         const unsigned long long emit = __ballot(has_a || has_b);
         if (emit == 0) return;
         const uint32_t n_a = has_a ? cnt - below : 0u;
-        const uint32_t v_cut = has_a ? value(below) : ltop;          // the value just above what stays / above item B
+        uint32_t v_cut = ltop;                                       // the value just above what stays / above item B: the walk over item A gives it
         const unsigned long long lt = (1ull << lane) - 1ull;
         const uint32_t rank = (uint32_t)__builtin_popcountll(emit & lt), lanes = (uint32_t)__builtin_popcountll(emit);
         for (uint32_t first = 0; first < lanes; first += kSlots) {
@@ -260,8 +245,9 @@ struct OutRuns {
                 if (mine && (b_item ? has_b : has_a)) {
                     const uint32_t at = b_item ? n_ra + (uint32_t)__builtin_popcountll(m_rb & lt)
                                                : (rag_a ? (uint32_t)__builtin_popcountll(m_ra & lt) : n_rag + (uint32_t)__builtin_popcountll(m_fa & lt));
-                    park_item(lds + kItemBase + kItemQ * at, rank - first, b_item ? 0u : below, b_item ? rest : n_a,
-                              b_item ? gl : gl + below, b_item ? v_cut : ltop);
+                    const uint32_t v_low = park_item(lds + kItemBase + kItemQ * at, rank - first, b_item ? 0u : below, b_item ? rest : n_a,
+                                                     b_item ? gl : gl + below, b_item ? v_cut : ltop);
+                    if (!b_item) v_cut = v_low;
                 }
             }
             wave_sync();

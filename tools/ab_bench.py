@@ -87,7 +87,9 @@ def main():
             if rep:
                 times.append(st.kernel_ms)
             else:
-                sums[name] = (int(d_pml[:nb].to(torch.int64).sum().item()), int(d_cid[:nb].to(torch.int64).sum().item()))
+                step = 1 << 28                      # in slices: an int64 copy of 1e10 values would not fit beside the index
+                sums[name] = (sum(int(d_pml[a:min(a + step, nb)].to(torch.int64).sum().item()) for a in range(0, nb, step)),
+                              sum(int(d_cid[a:min(a + step, nb)].to(torch.int64).sum().item()) for a in range(0, nb, step)))
             del d_pml, d_cid
     ref = sums[variants[0][0]]
     # a checksum only says something when there is another variant to compare with: with a single
