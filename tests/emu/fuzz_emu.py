@@ -42,7 +42,8 @@ def one(seed):
     bases, off = helpers.concat_reads(reads)
     ep, ec = oracle.OracleIndex(img).query_batch(bases, off)
     # line rows (4) and line rows with mismatch lines (5), at varying depths
-    fat = {0: (4, 5 | (4 << 8), 6), 1: (4 | (6 << 8), 5, 6 | (5 << 8)), 2: (5 | ((4 + seed // 3 % 5) << 8), 6 | ((4 + seed // 3 % 5) << 8))}[seed % 3]
+    k = (4 + seed // 3 % 5) << 8                     # look-ahead depth 4 .. 8
+    fat = {0: (4 | k, 5), 1: (5 | k, 6), 2: (6 | k, 4)}[seed % 3]
     for layout in (1, 2, 3) + fat:
         tbl = pkg.ColPml.from_bytes(img, layout=layout)
         p, c, _ = tbl.query_batch(bases, off)

@@ -22,10 +22,10 @@ import helpers  # noqa: E402
 
 pkg = load_package()
 pkg.LIB_PATH = os.path.join(HERE, "libcolbwt_emu.so")   # emulated build instead of the HIP one
-# opens that leave the layout to the engine use three-step rows here: the emulator runs one OS
-# thread per lane, and the line rows (persistent lanes, eight refinement levels) are exercised by
-# the explicit cases below
-os.environ["COLBWT_LAYOUT"] = "3"
+# opens that leave the layout to the engine use two-step rows here: the emulator runs one OS
+# thread per lane, and the kernels with persistent lanes (three-step rows, line rows: every lane of
+# a workgroup stays until the last read is done) are exercised by the explicit cases below
+os.environ["COLBWT_LAYOUT"] = "2"
 oracle = load_oracle()
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -35,12 +35,12 @@ MIS_LINES = 5                     # COLBWT_LAYOUT_MISMATCH_LINES (| steps << 8)
 MIS_DEEP = 6                      # COLBWT_LAYOUT_MISMATCH_LINES_DEEP (| steps << 8)
 
 
-def check(image, reads, label, wide=False, extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP)):
+def check(image, reads, label, wide=False, extra_layouts=(MIS_LINES,), base_layouts=(1, 2, 3)):
     image = bytes(image)
     bases, off = helpers.concat_reads(reads)
     ref = oracle.OracleIndex(image)
     epml, ecid = ref.query_batch(bases, off, wide=wide)
-    for layout in (1, 2, 3) + tuple(extra_layouts):   # one-step rows / K-step refined rows / line rows: identical results
+    for layout in tuple(base_layouts) + tuple(extra_layouts):   # one-step rows / K-step refined rows / line rows: identical results
         tbl = pkg.ColPml.from_bytes(image, layout=layout)
         assert tbl.info().layout == layout & 0xFF
         pml, cid, _ = tbl.query_batch(bases, off, wide=wide)
@@ -189,7 +189,7 @@ def main():
     reads = helpers.reads_from_text(text, 60, (1, 120), 0.05, seed=6, extra=b"Nacgt")
     reads += [np.zeros(0, np.uint8), np.frombuffer(b"A", np.uint8)]       # empty + 1-base reads
     reads += rand_reads(rng, 20, 1, 40)
-    check(img, reads, "true_bwt")
+    check(img, reads, "true_bwt", extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP))
 
     # 3. synthetic tables spanning several jump blocks; sub-run splits
     for rows, split, seed in ((700, 0, 1), (3000, 150, 2), (257, 300, 3), (256, 0, 4)):
@@ -197,9 +197,10 @@ def main():
         reads = helpers.backward_walk_reads(img, 40, 70, 0.02, seed=seed)
         reads += rand_reads(rng, 40, 0, 90)
         reads += rand_reads(rng, 10, 1, 50, alphabet=b"ACGTN\x01")        # absent byte + terminator
-        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS, MIS_LINES | (6 << 8), MIS_DEEP | (7 << 8)), 257: (LINE_ROWS | (5 << 8), MIS_LINES | (4 << 8), MIS_DEEP | (4 << 8))}.get(rows, (MIS_DEEP,)))
+        check(img, reads, f"synth_{rows}_{split}", extra_layouts={700: (LINE_ROWS, MIS_LINES | (6 << 8), MIS_DEEP | (7 << 8)), 257: (LINE_ROWS | (5 << 8), MIS_LINES | (4 << 8), MIS_DEEP | (4 << 8))}.get(rows, ()))
     img = pkg.synth_index(2500, mean_len=6, split_permille=50, seed=8, thr_mode=1)   # thresholds inside rows: cut out
-    check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs")
+    check(img, helpers.backward_walk_reads(img, 60, 80, 0.05, seed=8) + rand_reads(rng, 30, 0, 90), "synth_thr_between_runs",
+          extra_layouts=(MIS_LINES, MIS_DEEP | (4 << 8)))                            # origin rows cut at thresholds; depth K straddles
 
     # 4. rare character far away: scans must leave the block and use the jump tables
     r = 2000
@@ -219,7 +220,7 @@ def main():
     for label, alpha in (("hints_sigma4", b"ACGT"), ("hints_sigma5", b"\x01ACGT"), ("nohints_sigma7", b"\x01ACGNTac")):
         img = helpers.random_table(rng, 1500, alphabet=alpha)
         check(img, rand_reads(rng, 80, 1, 70, alphabet=alpha + b"N"), label,
-              extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP) if label == "nohints_sigma7" else (MIS_LINES | (5 << 8), MIS_DEEP | (6 << 8)))
+              extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP) if label == "nohints_sigma7" else (MIS_LINES | (5 << 8),))
 
     # 5. long runs: len >= 65535 (len16 escape) incl. the last row, offsets near 2^16
     r = 600
@@ -232,14 +233,16 @@ def main():
     offset = offset & np.uint64(0xFFFF)            # what the 16-bit field keeps (LF_table.hpp:39)
     thr = rng.integers(0, n, size=r)
     img = helpers.pack_col_pml(r, n, chars, idx, interval, offset, rng.integers(0, 256, size=r), thr)
-    check(img, rand_reads(rng, 50, 1, 80), "long_runs")
+    check(img, rand_reads(rng, 50, 1, 80), "long_runs", extra_layouts=(LINE_ROWS, MIS_LINES))
 
     # 6. u32 PML: a read longer than 65535 bases
     img = pkg.synth_index(500, mean_len=4, split_permille=0, seed=9)
     long_read = helpers.backward_walk_reads(img, 1, 66000, 0.0005, seed=10)
-    check(img, long_read + rand_reads(rng, 3, 1, 30), "wide_pml", wide=True, extra_layouts=())
+    # (one lane per read and no persistent lanes: the kernels of the one- and two-step rows; the others
+    # take the same code path on the short reads below)
+    check(img, long_read + rand_reads(rng, 3, 1, 30), "wide_pml", wide=True, extra_layouts=(), base_layouts=(1, 2))
     short = [long_read[0][-900:]] + rand_reads(rng, 3, 1, 30)             # the u32 kernels of the line rows, small
-    check(img, short, "wide_pml_line_rows", wide=True)
+    check(img, short, "wide_pml_line_rows", wide=True, extra_layouts=(LINE_ROWS, MIS_LINES, MIS_DEEP))
     try:
         bases, off = helpers.concat_reads(long_read)
         pkg.ColPml.from_bytes(bytes(img)).query_batch(bases, off, wide=False)
@@ -279,8 +282,8 @@ def main():
 
     # 9. HBM budget (COLBWT_HBM_BUDGET_MB): AUTO falls back to the deepest layout that fits; an
     #    explicit layout that does not fit is COLBWT_ERR_NOMEM; nothing is left allocated
-    img = pkg.synth_index(2_500, mean_len=8, split_permille=0, seed=5)
-    reads = helpers.backward_walk_reads(img, 40, 60, 0.02, seed=5)
+    img = pkg.synth_index(1_000, mean_len=8, split_permille=0, seed=5)
+    reads = helpers.backward_walk_reads(img, 30, 60, 0.02, seed=5)
     bases, off = helpers.concat_reads(reads)
     epml, ecid = oracle.OracleIndex(bytes(img)).query_batch(bases, off)
     full = {}
@@ -308,10 +311,10 @@ def main():
         raise SystemExit("a three-step open beyond the budget must fail")
     except pkg.ColbwtError as e:
         assert e.code == -6, e
-    os.environ["COLBWT_HBM_BUDGET_MB"] = "0.05"
+    os.environ["COLBWT_HBM_BUDGET_MB"] = "0.01"
     try:
         pkg.ColPml.from_bytes(img, layout=0)
-        raise SystemExit("nothing fits in 50 KB")
+        raise SystemExit("nothing fits in 10 KB")
     except pkg.ColbwtError as e:
         assert e.code == -6, e
     del os.environ["COLBWT_HBM_BUDGET_MB"]
