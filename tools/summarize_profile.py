@@ -23,7 +23,7 @@ import shutil
 import sys
 
 
-KERNEL_SOURCES = ("fat2_query.hip", "fat_cursor.h", "fat_query.hip", "fat_layout.h", "fat_build.hip", "lane_io.h", "sk_query.hip", "sk_layout.h", "query_kernels.hip",
+KERNEL_SOURCES = ("fat2_query.hip", "fat_cursor.h", "lane_out.h", "fat_query.hip", "fat_layout.h", "fat_build.hip", "lane_io.h", "sk_query.hip", "sk_layout.h", "query_kernels.hip",
                   "lf_device.h", "device_layout.h")
 
 
