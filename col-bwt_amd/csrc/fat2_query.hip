@@ -47,8 +47,10 @@ constexpr uint32_t kOffMis1 = 0xFFFFFFFBu;      // ... second half.  In this sta
 
 // slot (0..2) of read byte c among the mismatch entries of an origin row whose character is `own`,
 // 3 = none (c or too many characters beyond the four most frequent)
-__device__ __forceinline__ uint32_t mis_slot(uint32_t top4, uint32_t own, uint32_t c) {
-    const uint32_t aidx = fat_top_index(top4, own), cidx = fat_top_index(top4, c);   // 4 = not among the four
+// top: byte -> its index among the four most frequent characters, 4 = none of them (a table in LDS:
+// the three uses per trip were 60 vector instructions of compares and selects)
+__device__ __forceinline__ uint32_t mis_slot(const uint8_t *top, uint32_t own, uint32_t c) {
+    const uint32_t aidx = top[own], cidx = top[c];
     const uint32_t slot = cidx < aidx ? cidx : cidx - 1;
     return cidx < 4 && slot < kFatSlots ? slot : kFatSlots;
 }
@@ -62,11 +64,13 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
     __shared__ uint4 s_stage[kWaves][8][64];       // per wave: instruction q's 64 x 16 bytes
     __shared__ uint4 s_win[kWaves][4][64];         // read bytes (lane_io.h LaneWindow)
     __shared__ uint32_t s_claim;                   // the workgroup's chunk counter (ChunkPlan)
+    __shared__ uint8_t s_top[256];                 // byte -> index among the four most frequent characters (mis_slot)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, g8 = lane & ~7u, p = lane & 7u;
     uint32_t *const s_jx = reinterpret_cast<uint32_t *>(&s_stage[wave][7][48]);   // 64 dwords
     ChunkPlan plan;
     plan.init(n_reads, big_reads, tail_permille);
     if (threadIdx.x == 0) s_claim = 0;
+    s_top[threadIdx.x] = (uint8_t)fat_top_index(T.top4, threadIdx.x);
     __syncthreads();
     uint32_t *const claim = &s_claim;
     ReadCursor rc;
@@ -157,7 +161,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                 uint32_t oc = 4;                             // which outcome the second base is (4: not resolved here)
                 if (left >= 2) {
                     const uint32_t c2 = (uint32_t)(W >> 48) & 0xFFu;
-                    const uint32_t s2 = mis_slot(T.top4, t1, c2);
+                    const uint32_t s2 = mis_slot(s_top, t1, c2);
                     if (c2 == t1) oc = 0;                    // :516 one step later
                     else if (s2 < kFatSlots && ((v1 >> s2) & 1u)) oc = 1 + s2;
                 }
@@ -198,7 +202,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                         uint32_t sn = kFatSlots;
                         if (left > seen) {
                             const uint32_t cn = (uint32_t)(W >> (8u * (7u - seen))) & 0xFFu;
-                            if (cn != nch) sn = mis_slot(T.top4, nch, cn);
+                            if (cn != nch) sn = mis_slot(s_top, nch, cn);
                         }
                         if (sn < kFatSlots && ((nv >> sn) & 1u)) {
                             const uint32_t e = nrho * kFatSlots + sn;    // straight on to the next entry
@@ -253,7 +257,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                         // (:516 / :520): depth d = run + 1 <= K, the base after the consumed ones
                         const uint32_t d = run + 1u, sh = 8u * (8u - d);
                         const uint32_t c = (uint32_t)(W >> (sh + 8u * skip)) & 0xFFu;
-                        const uint32_t s = mis_slot(T.top4, (uint32_t)(CH >> sh) & 0xFFu, c);
+                        const uint32_t s = mis_slot(s_top, (uint32_t)(CH >> sh) & 0xFFu, c);
                         if (s < kFatSlots && ((r1.w >> (3u * run + s)) & 1u)) {
                             const uint32_t rho = reinterpret_cast<const uint32_t *>(&my_row[((kFatRho / 16) + (run >> 2)) ^ p])[run & 3u];
                             e_next = rho * kFatSlots + s;
