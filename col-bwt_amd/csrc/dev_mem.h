@@ -1,5 +1,6 @@
 // dev_mem.h -- device allocations of the index builder: every table and every temporary of
-// Index::load / build_sk goes through dev_alloc / dev_free, so that
+// Index::load / build_sk goes through dev_alloc / dev_free (COLBWT_ALLOC_LOG=1 lists the large ones
+// on stderr), so that
 //   * a failed build frees what it had allocated (DevPtr is RAII; the failure paths of the
 //     K-step refinement used to leak their temporaries -- exactly where the AUTO layout
 //     fallback needs the HBM back), and
@@ -15,6 +16,8 @@
 #include <time.h>
 
 #include <algorithm>
+
+#include "dev_vmm.h"
 
 namespace colbwt {
 
@@ -43,8 +46,28 @@ inline hipError_t dev_alloc(void **p, uint64_t bytes) {
     *p = nullptr;
     DevBudget *b = current_budget();
     if (b && (bytes > b->limit || b->used > b->limit - bytes)) return hipErrorOutOfMemory;
-    const hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    // large arrays: address ranges over the device's granule store (dev_vmm.h), so that an open does not
+    // hand memory back to the driver and wait for it to be wiped; the rest: hipMalloc
+    const bool ranged = vmm_takes(bytes);
+    hipError_t e = ranged ? vmm_alloc(p, bytes) : hipMalloc(p, bytes ? bytes : 1);
+    if (e != hipSuccess && vmm_idle_bytes() != 0) {
+        // the room may be in granules the store keeps for its next array
+        int dev = 0;
+        (void)hipGetLastError();
+        if (hipGetDevice(&dev) == hipSuccess) vmm_trim(dev);
+        e = ranged ? vmm_alloc(p, bytes) : hipMalloc(p, bytes ? bytes : 1);
+    }
+    if (e != hipSuccess && ranged) {   // the store is out of addresses (or the runtime lacks the API): plain memory
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
     if (e != hipSuccess) {
+        if (getenv("COLBWT_ALLOC_LOG")) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            fprintf(stderr, "[colbwt alloc] ! %8.2f GB failed (%s, %s): device reports %.2f GB free\n", bytes * 1e-9, hipGetErrorString(e),
+                    ranged ? "granule store" : "hipMalloc", free_b * 1e-9);
+        }
         *p = nullptr;
         (void)hipGetLastError();   // the caller reports `e`; do not leave it for a later hipGetLastError
         return e;
@@ -52,6 +75,13 @@ inline hipError_t dev_alloc(void **p, uint64_t bytes) {
     if (b) {
         b->used += bytes;
         if (b->used > b->peak) b->peak = b->used;
+    }
+    if (getenv("COLBWT_ALLOC_LOG") && bytes >= (64u << 20)) {
+        fprintf(stderr, "[colbwt alloc] + %8.2f GB  %p  used %8.2f", bytes * 1e-9, *p, b ? b->used * 1e-9 : 0.0);
+        const VmmLast &l = vmm_last();
+        if (ranged) fprintf(stderr, "   granules: %llu reused, %llu created in %.3f s, mapped in %.3f s, access set in %.3f s",
+                            (unsigned long long)l.reused, (unsigned long long)l.created, l.create_s, l.map_s, l.access_s);
+        fprintf(stderr, "\n");
     }
     return hipSuccess;
 }
@@ -62,7 +92,7 @@ inline hipError_t dev_alloc(void **p, uint64_t bytes) {
 inline uint64_t dev_available_bytes() {
     size_t free_b = 0, total_b = 0;
     uint64_t avail = ~0ull;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = free_b;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) avail = free_b + vmm_idle_bytes();   // idle granules are the store's to reuse or return
     else (void)hipGetLastError();
     const DevBudget *b = current_budget();
     if (b && b->limit != ~0ull) avail = std::min<uint64_t>(avail, b->limit > b->used ? b->limit - b->used : 0);
@@ -71,7 +101,8 @@ inline uint64_t dev_available_bytes() {
 
 inline void dev_free(void *p, uint64_t bytes) {
     if (!p) return;
-    (void)hipFree(p);
+    if (getenv("COLBWT_ALLOC_LOG") && bytes >= (64u << 20)) fprintf(stderr, "[colbwt alloc] - %8.2f GB  %p\n", bytes * 1e-9, p);
+    if (!vmm_free(p)) (void)hipFree(p);
     DevBudget *b = current_budget();
     if (b) b->used = b->used > bytes ? b->used - bytes : 0;
 }

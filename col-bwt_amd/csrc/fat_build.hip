@@ -387,6 +387,9 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
     // is beyond what can still be allocated the build cannot succeed -- say so after the counting
     // pass, before tens of GB are allocated and filled only to be given back.
     if (total * kFatRowBytes > dev_available_bytes()) {
+        if (getenv("COLBWT_ALLOC_LOG"))
+            fprintf(stderr, "[colbwt alloc] ? %llu rows x 128 bytes = %.2f GB against %.2f GB available\n", (unsigned long long)total,
+                    total * 128e-9, dev_available_bytes() * 1e-9);
         err = "line-row layout: " + std::to_string(total) + " rows at a refinement level need more HBM than is available";
         return COLBWT_ERR_NOMEM;
     }

@@ -76,6 +76,7 @@ namespace {
 // the budget of the open running on this thread (dev_mem.h), dropped when the load returns
 struct BudgetScope {
     DevBudget b;
+    VmmScope keep_granules;   // freed arrays' memory stays with the process until the open returns (dev_vmm.h)
     BudgetScope() { b.limit = env_budget_bytes(); current_budget() = &b; }
     ~BudgetScope() { current_budget() = nullptr; }
 };

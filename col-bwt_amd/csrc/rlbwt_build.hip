@@ -263,6 +263,7 @@ __global__ void gather_u32_kernel(const uint32_t *src, const uint32_t *at, uint6
 
 struct BudgetScope {
     DevBudget b;
+    VmmScope keep_granules;   // freed arrays' memory stays with the process until the open returns (dev_vmm.h)
     DevBudget *prev;
     BudgetScope() : prev(current_budget()) { b.limit = env_budget_bytes(); current_budget() = &b; }
     ~BudgetScope() { current_budget() = prev; }

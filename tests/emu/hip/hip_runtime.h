@@ -9,6 +9,7 @@
 // other; __syncthreads / __ballot are real rendezvous among those threads.
 #pragma once
 #include <stdint.h>
+#include <sys/mman.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,7 +37,7 @@ struct dim3 {
 #define __launch_bounds__(...)
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
 typedef struct emu_stream *hipStream_t;
 typedef struct emu_event { double t; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
@@ -162,6 +163,33 @@ static inline hipError_t hipMalloc(void **p, size_t n) {
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) { *free_b = *total_b = (size_t)1 << 40; return hipSuccess; }
+// virtual memory management (csrc/dev_vmm.h): a reserved range is anonymous host memory, granules are
+// heap objects so that ASan sees a granule released twice or never
+typedef struct emu_granule { size_t size; } *hipMemGenericAllocationHandle_t;
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; hipMemLocation location; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+namespace emu { inline long &granules_alive() { static long n = 0; return n; } }
+static inline hipError_t hipMemAddressReserve(void **p, size_t n, size_t, void *, unsigned long long) {
+    void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);   // terabytes of addresses, pages on touch
+    *p = m == MAP_FAILED ? nullptr : m;
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipMemAddressFree(void *p, size_t n) { munmap(p, n); return hipSuccess; }
+static inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *h, size_t n, const hipMemAllocationProp *, unsigned long long) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); *h = new emu_granule{n}; ++emu::granules_alive(); return hipSuccess;
+}
+static inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); delete h; --emu::granules_alive(); return hipSuccess;
+}
+static inline hipError_t hipMemMap(void *, size_t n, size_t, hipMemGenericAllocationHandle_t h, unsigned long long) {
+    std::lock_guard<std::mutex> g(emu::atomic_mu); if (n != h->size) abort(); return hipSuccess;
+}
+static inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipSuccess; }
+static inline hipError_t hipMemUnmap(void *, size_t) { return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 enum { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1 };

@@ -644,6 +644,33 @@ def test_two_replicas_shard_every_batch(pkg, oracle, tmp_path):
             assert open(f"{fa2}.{ext}", "rb").read() == open(f"{fa}.o{ext}", "rb").read()
 
 
+def test_granule_store_small_tables(pkg, oracle, tmp_path):
+    """csrc/dev_vmm.h: arrays of 512 MiB and more are address ranges over recycled granules of physical
+    memory, which the tables of this tier never reach.  Here the knobs are shrunk (granules of 2 MiB,
+    every array of 1 MiB and more through the store) in child processes -- the store reads them once --
+    and `pml_query` must write the oracle's bytes for every layout: refinement levels, final tables and
+    the run-time tables all live on granules that earlier arrays of the same open gave back."""
+    import subprocess
+    rng = np.random.default_rng(404)
+    image = pkg.synth_index(400_000, mean_len=7, split_permille=80, seed=404)
+    reads = helpers.backward_walk_reads(image.tobytes(), 1500, 150, 0.02, seed=405) + _rand_reads(rng, 500, 0, 300)
+    fa = tmp_path / "reads.fa"
+    helpers.write_fasta(fa, reads, width=80)
+    oracle.OracleIndex(image.tobytes()).pml_query_files(str(fa), str(fa) + ".opml", str(fa) + ".ocid")
+    (tmp_path / "tbl.col_pml").write_bytes(image.tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for layout in (5, 4, 3, 2, 1):
+        fa2 = tmp_path / f"store_{layout}.fa"
+        shutil.copy(fa, fa2)
+        env = dict(os.environ, COLBWT_VMM_GRANULE_MB="2", COLBWT_VMM_MIN_MB="1", COLBWT_ALLOC_LOG="1", COLBWT_LAYOUT=str(layout))
+        out = subprocess.run([os.path.join(root, "col-bwt_amd", "pml_query"), "-v", "-p", str(fa2), str(tmp_path / "tbl")],
+                             capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert " failed (" not in out.stderr, out.stderr
+        for ext in ("pml", "cid"):
+            assert open(f"{fa2}.{ext}", "rb").read() == open(f"{fa}.o{ext}", "rb").read(), (layout, ext)
+
+
 def test_binary_containers_round_trip(pkg, oracle, tmp_path):
     """`.pml.bin` / `.cid.bin` (include/colbwt.h: Movi-like record shape, unverified against Movi --
     the reference names these outputs, scripts/col-bwt.py:194, but their writer is not in its
