@@ -42,13 +42,31 @@ inline uint64_t env_budget_bytes() {
     return (uint64_t)(mb * 1048576.0);
 }
 
+// The table the query kernel fetches from stays a hipMalloc block: granules are created from whatever
+// memory is free at that moment, and on a box whose previous process has just exited that is the
+// scraps between regions still being wiped -- consecutive bench.py processes on one box measured
+// 10.7-11.1 ms per launch on a fresh box but 11.7-12.6 ms later, against 10.9-11.5 ms throughout for a
+// hipMalloc table, which waits for the wipe and gets the memory whole
+// (profiles/r03w_bench_sequence.jsonl).  The builder's temporaries do not care.
+inline bool &plain_alloc() {
+    static thread_local bool plain = false;
+    return plain;
+}
+struct PlainAllocScope {
+    bool prev;
+    explicit PlainAllocScope(bool on = true) : prev(plain_alloc()) { plain_alloc() = prev || on; }
+    ~PlainAllocScope() { plain_alloc() = prev; }
+    PlainAllocScope(const PlainAllocScope &) = delete;
+    PlainAllocScope &operator=(const PlainAllocScope &) = delete;
+};
+
 inline hipError_t dev_alloc(void **p, uint64_t bytes) {
     *p = nullptr;
     DevBudget *b = current_budget();
     if (b && (bytes > b->limit || b->used > b->limit - bytes)) return hipErrorOutOfMemory;
     // large arrays: address ranges over the device's granule store (dev_vmm.h), so that an open does not
     // hand memory back to the driver and wait for it to be wiped; the rest: hipMalloc
-    const bool ranged = vmm_takes(bytes);
+    const bool ranged = vmm_takes(bytes) && !plain_alloc();
     hipError_t e = ranged ? vmm_alloc(p, bytes) : hipMalloc(p, bytes ? bytes : 1);
     if (e != hipSuccess && vmm_idle_bytes() != 0) {
         // the room may be in granules the store keeps for its next array

@@ -538,7 +538,10 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, int mismatch_lin
         SK_TRY(hipStreamSynchronize(0));
         clock.lap("  origin rows, entry flags");
     }
-    SK_TRY(buf.lines.alloc(((uint64_t)r + 1 + mis_lines) * kFatRowBytes));
+    {
+        PlainAllocScope whole;             // the table the query fetches from: one hipMalloc block (dev_mem.h)
+        SK_TRY(buf.lines.alloc(((uint64_t)r + 1 + mis_lines) * kFatRowBytes));
+    }
     clock.lap("  lines allocated");
     uint8_t *const d_lines = buf.lines.as<uint8_t>();
     SK_TRY(hipMemset(d_lines + (uint64_t)r * kFatRowBytes, 0, kFatRowBytes));

@@ -125,7 +125,10 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
 
     // r rows + the sentinel, padded to whole 128-byte lines (8 rows) so line-wide loads stay in bounds
     const uint64_t rows_alloc = ((r + 1 + 7) & ~7ull) * sizeof(uint4);
-    HIP_TRY(d_rows_.alloc(rows_alloc));
+    {
+        PlainAllocScope whole;             // the one-step layout's query table (dev_mem.h)
+        HIP_TRY(d_rows_.alloc(rows_alloc));
+    }
     HIP_TRY(hipMemset(d_rows_.get(), 0, rows_alloc));
     HIP_TRY(d_idx_.alloc((r + 1) * sizeof(uint64_t)));
     HIP_TRY(d_thr_.alloc(r * sizeof(uint64_t)));

@@ -256,7 +256,10 @@ int build_level(const Src &S, uint64_t src_rows, const uint8_t *d_cmap, uint32_t
 
     constexpr uint32_t rpl = SKGeom<K>::kRowsPerLine;
     const uint64_t nlines = ((uint64_t)r_new + 1 + rpl - 1) / rpl + 1;
-    SK_TRY(buf.lines.alloc(nlines * 128));
+    {
+        PlainAllocScope whole(finish);     // the table the query fetches from: one hipMalloc block (dev_mem.h)
+        SK_TRY(buf.lines.alloc(nlines * 128));
+    }
     SK_TRY(hipMemset(buf.lines.get(), 0, nlines * 128));
     SK_TRY(buf.idx.alloc(((uint64_t)r_new + 4) * sizeof(uint64_t)));
     SK_TRY(hipMemset(buf.idx.get(), 0xFF, ((uint64_t)r_new + 4) * sizeof(uint64_t)));
