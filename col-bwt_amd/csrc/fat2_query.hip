@@ -148,7 +148,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
         if (!live || have == 0) FAT2_STAT(5);
         if (live && have != 0) {
             const uint64_t W = win.get8(my_win, lane, g);    // byte 7 = the next base
-            const uint64_t left = k < have ? k : have;       // bases this trip may consume
+            const uint32_t left = k < have ? (uint32_t)k : have;   // bases this trip may consume (<= 64: 32-bit compares below)
             if (o == kOffMis0 || o == kOffMis1) {
                 // ---- a mismatch entry: the next base did not match where the lane came from
                 // (col_bwt.hpp:520-523: length 0, threshold_step, LF), the one after it is open
@@ -248,7 +248,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                     // ---- the next 8 read bases against the 8 characters the row's positions meet
                     const uint64_t X = skip ? ((W >> 8) ^ CH) & 0x00FFFFFFFFFFFFFFull : W ^ CH;
                     const uint32_t run = matching_top_bytes(X);          // LF steps that match, the skipped one included
-                    const uint32_t cap = left + skip < (uint64_t)K ? (uint32_t)left + skip : (uint32_t)K;
+                    const uint32_t cap = left + skip < (uint32_t)K ? left + skip : (uint32_t)K;
                     uint32_t steps = run < cap ? run : cap;
                     bool own_jump = true, to_entry = false;
                     uint32_t e_next = 0, carry = 0;
@@ -282,7 +282,7 @@ void fat2_query_kernel(FatTable T, const uint8_t *__restrict__ bases, const uint
                             // c occurs nowhere: (interval, offset) unchanged (:533-534), LF proceeds
                             // from this row; length restarts at 0
                             const uint32_t st = matching_top_bytes(X & 0x00FFFFFFFFFFFFFFull);
-                            const uint32_t cap0 = left < (uint64_t)K ? (uint32_t)left : (uint32_t)K;
+                            const uint32_t cap0 = left < (uint32_t)K ? left : (uint32_t)K;
                             steps = st < cap0 ? st : cap0;
                             consumed = steps;
                             l_new = steps - 1;

@@ -270,11 +270,13 @@ struct LaneWindow {
     // the 8 read bytes ending at g as one little-endian word: byte 7 = base g, byte 0 = base g - 7
     // (bytes below the window are whatever it holds: callers cap what they use by `avail`)
     __device__ __forceinline__ uint64_t get8(const uint4 (*win)[64], uint32_t lane, uint64_t g) const {
-        const uint32_t b = ((uint32_t)g - wb) & 63u, d = b >> 2;
-        const uint32_t x2 = dword(win, lane, d), x1 = dword(win, lane, (d - 1u) & 15u), x0 = dword(win, lane, (d - 2u) & 15u);
-        const uint32_t sh = 8u * ((b & 3u) + 1u);                     // 8 .. 32
-        const uint64_t l64 = (uint64_t)x0 | ((uint64_t)x1 << 32);
-        return (l64 >> sh) | ((uint64_t)x2 << (64u - sh));
+        // bytes [e - 8, e) of the window, e = index of g + 1: they start r = e & 3 bytes into dword
+        // e / 4 - 2, so each half is one v_alignbyte of two neighbouring dwords (r = 0: the upper
+        // dword of each pair is not used, and e / 4 may then be 16 -- any dword will do)
+        const uint32_t e = (((uint32_t)g - wb) & 63u) + 1u, d = e >> 2, r = e & 3u;
+        const uint32_t x2 = dword(win, lane, d & 15u), x1 = dword(win, lane, (d - 1u) & 15u), x0 = dword(win, lane, (d - 2u) & 15u);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(x1, x0, r), hi = __builtin_amdgcn_alignbyte(x2, x1, r);
+        return (uint64_t)lo | ((uint64_t)hi << 32);
     }
 };
 

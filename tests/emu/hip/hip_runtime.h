@@ -145,6 +145,9 @@ static inline uint32_t atomicMin(uint32_t *p, uint32_t v) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
 
+static inline uint32_t __builtin_amdgcn_alignbyte(uint32_t hi, uint32_t lo, uint32_t r) {   // v_alignbyte_b32
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (r & 3u)));
+}
 static inline const char *hipGetErrorString(hipError_t) { return "emu error"; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 using std::max;
