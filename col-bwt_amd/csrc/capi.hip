@@ -558,11 +558,13 @@ int colbwt_index_open_memory_layout(const void *bytes, uint64_t len, const colbw
     colbwt_index *idx = new (std::nothrow) colbwt_index();
     if (!idx) return fail(COLBWT_ERR_NOMEM, "out of host memory");
     std::string err;
-    int rc = idx->ix.load((const uint8_t *)bytes, len, device, layout, err, steps);
+    // AUTO's first choice: mismatch lines, with deep entries when the table leaves room for batches
+    const bool deep_if_room = automatic && layout == COLBWT_LAYOUT_MISMATCH_LINES && getenv("COLBWT_LAYOUT") == nullptr;
+    int rc = idx->ix.load((const uint8_t *)bytes, len, device, deep_if_room ? kLayoutMismatchLinesAuto : layout, err, steps);
     if (rc == COLBWT_ERR_NOMEM && automatic) {
         // The table does not fit that way (HBM, or more than 2^32-2 refined rows): the ladder of
-        // smaller layouts -- deep mismatch lines, mismatch lines, line rows at K = 8, 6, 4, three-, two-,
-        // one-step rows.
+        // smaller layouts -- line rows at K = 8, 6, 4, three-, two-, one-step rows (the first attempt
+        // already went from deep to plain mismatch entries by itself when the deep ones had no room).
         // A line-row build says at which refinement level it gave up (after that level's counting
         // pass, before anything of it was allocated): candidates that have to pass the same level
         // are not tried at all, so an index far too large for line rows costs one counting pass.

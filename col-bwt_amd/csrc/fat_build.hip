@@ -426,6 +426,9 @@ int refine_plain(const Src &S, uint64_t src_rows, uint64_t n, PlainLevel &out, P
     return COLBWT_OK;
 }
 
+// HBM an AUTO open leaves free (of what it could still allocate) when it chooses deep mismatch entries.
+constexpr uint64_t kDeepReserve = 32ull << 30;
+
 template <int K>
 int build_fat_steps(const DevTable &T1, const HintChars &chars, int mismatch_lines, FatTable &out, FatBuffers &buf, std::string &err,
                     const std::function<void()> &source_done, int &failed_level) {
@@ -516,6 +519,13 @@ int build_fat_steps(const DevTable &T1, const HintChars &chars, int mismatch_lin
         {
             const int rc = exclusive_scan_u32(d_rho, r, n_rho, err);
             if (rc != COLBWT_OK) return rc;
+        }
+        if (mismatch_lines == 3) {
+            // AUTO: deep entries (6 % faster on C2, profiles/r03y_deep_vs_plain_entries_last_build.jsonl)
+            // when the table then still leaves kDeepReserve of what can be allocated now -- room for
+            // read batches and their results; else the 64-byte entries (half the entry table)
+            const uint64_t deep_bytes = ((uint64_t)r + 1 + n_rho * kFatSlots) * kFatRowBytes;
+            mismatch_lines = deep_bytes + kDeepReserve <= dev_available_bytes() ? 2 : 1;
         }
         const uint32_t entry_shift = mismatch_lines == 2 ? 7u : 6u;           // 2: deep entries, a line each
         mis_lines = ((n_rho * kFatSlots << entry_shift) + kFatRowBytes - 1) / kFatRowBytes;

@@ -13,6 +13,10 @@
 
 namespace colbwt {
 
+// Index::load only (not a public layout): mismatch lines, deep when the table then still leaves room
+// for batches (fat_build.hip kDeepReserve), plain otherwise -- what COLBWT_LAYOUT_AUTO asks for first.
+constexpr int kLayoutMismatchLinesAuto = 7;
+
 struct IndexError {
     int code;
     std::string msg;
@@ -28,7 +32,8 @@ public:
     // `bytes` is the whole .col_pml image (header + rows) in host memory.
     // Returns 0 or a COLBWT_ERR_* code with `err` filled.
     // layout: 1 = one-step (device_layout.h); 2 / 3 = K-step (sk_layout.h, refined from 1);
-    // 4 = line rows (fat_layout.h) with `steps` own steps; 5 = the same with mismatch lines; 6 = with deep ones.
+    // 4 = line rows (fat_layout.h) with `steps` own steps; 5 = the same with mismatch lines; 6 = with deep ones;
+    // kLayoutMismatchLinesAuto = 6 when there is room, else 5 (layout() says which).
     int load(const uint8_t *bytes, uint64_t len, int device, int layout, std::string &err, int steps = 0);
 
     const DevTable &table() const { return tbl_; }

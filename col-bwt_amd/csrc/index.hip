@@ -246,13 +246,13 @@ int Index::load(const uint8_t *bytes, uint64_t len, int device, int layout, std:
                 return rc;
             }
             layout_ = layout;
-        } else if (layout >= 4 && layout <= 6) {
+        } else if (layout >= 4 && layout <= kLayoutMismatchLinesAuto) {
             rc = build_fat(tbl_, hc, steps, layout - 4, tblf_, buff_, err, [this] { release_one_step(); }, &fat_failed_level_);
             if (rc != COLBWT_OK) {
                 release();
                 return rc;
             }
-            layout_ = layout;
+            layout_ = tblf_.slot_line0 == 0 ? 4 : (tblf_.entry_shift == 7 ? 6 : 5);   // what the table became
         }
     }
     clock.lap("K-step / line-row layout");

@@ -85,7 +85,9 @@ struct FatBuffers {
     void release();
 };
 // Line rows with `steps` own steps (fat_build.hip), with in-row mismatch slots (mismatch_lines = 0),
-// with mismatch lines (1) or with deep ones (2: fat_layout.h); same contract as build_sk.
+// with mismatch lines (1), with deep ones (2: fat_layout.h), or with deep ones when the table then
+// still leaves room for batches and plain ones otherwise (3: what AUTO asks for; out.entry_shift
+// says which it became); same contract as build_sk.
 // fat_steps_supported: the step counts compiled in.  On failure *failed_level (nullable) says how
 // far the build got: the refinement level (2 .. steps) that could not be built -- a build with
 // at least that many steps fails the same way -- or steps + 1 when the levels fit and the final

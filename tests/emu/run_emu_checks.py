@@ -293,7 +293,13 @@ def main():
         tbl.close()
     assert full[1] < full[2] < full[3] < full[4] < full[5] < full[6]
     del os.environ["COLBWT_LAYOUT"]                   # the engine's own choice from here on
-    # the ladder (capi.hip): mismatch lines, line rows at K = 8 / 6 / 4, three-, two-, one-step rows (deep mismatch lines: on request)
+    # no budget: deep mismatch entries, there is room for them (fat_build.hip kDeepReserve); any budget
+    # below the reserve: plain ones, then the ladder (capi.hip): line rows at K = 8 / 6 / 4, three-, two-, one-step rows
+    tbl = pkg.ColPml.from_bytes(img, layout=0)
+    assert tbl.info().layout == MIS_DEEP, tbl.info().layout
+    pml, cid, _ = tbl.query_batch(bases, off)
+    assert np.array_equal(pml, epml) and np.array_equal(cid, ecid)
+    tbl.close()
     for budget_mb, expect in ((10_000, (5,)), (full[5] / 2**20 - 0.01, (4,)), (full[4] / 2**20 - 0.01, (4, 3)),
                               (full[3] / 2**20 - 0.01, (2,)), (full[2] / 2**20 - 0.01, (1,))):
         os.environ["COLBWT_HBM_BUDGET_MB"] = str(budget_mb)
