@@ -118,9 +118,10 @@ int colbwt_index_open_memory(const void *col_pml_bytes, uint64_t len, const colb
 /* MISMATCH_LINES_DEEP: the same with 128-byte entries that also resolve the base after those two when
  * it matches -- between two mismatches of a stretch there is often exactly one matching base, and
  * with it resolved in the entry the lane goes from entry to entry.  MISMATCH_LINES + ~190 bytes per
- * row of the file.  Measured on C2: 37.1 line fetches per read instead of 40.7 and the same launch
- * time (the kernel is bound by its vector instructions as much as by its fetches):
- * available on request, not what AUTO picks. */
+ * row of the file.  Measured on C2: 37.1 line fetches per read instead of 40.7, 10.6-11.0 ms per
+ * launch instead of 11.5-11.6.  AUTO takes the deep entries when the table with
+ * them still leaves 32 GB of what the open could allocate (HBM, COLBWT_HBM_BUDGET_MB) for batches
+ * and their results, the 64-byte entries otherwise; asking for MISMATCH_LINES gets the 64-byte ones. */
 #define COLBWT_LAYOUT_MISMATCH_LINES_DEEP 6
 #define COLBWT_LAYOUT_MISMATCH_LINES_DEEP_STEPS(K) (COLBWT_LAYOUT_MISMATCH_LINES_DEEP | ((K) << 8))
 int colbwt_index_open_layout(const char *prefix_or_file, const colbwt_widths *widths, int device, int layout,
