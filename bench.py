@@ -79,6 +79,12 @@ def main():
     t0 = time.time()
     image = pkg.synth_index(args.rows, mean_len=8, split_permille=0, seed=42)
     t_gen = time.time() - t0
+    # Rank 0 also holds every rank's rebuilt results (world x 3 bytes per base, + packed copies and the
+    # check's slices) next to its own batch.  AUTO's deep mismatch entries leave ~80 GB of the 309 GB
+    # next to the C2 index: beyond 40 GB of such buffers (N = 8 here) every rank opens with the 64-byte
+    # entries instead (38 GB less; the same layout on all ranks, decided from world and batch size alone).
+    if world > 1 and world * n_bases * 7 // 2 + 8 * n_bases > (40 << 30):
+        os.environ.setdefault("COLBWT_LAYOUT", "5")
     t0 = time.time()
     tbl = pkg.ColPml.from_bytes(image, device=local_rank)
     t_load = time.time() - t0
@@ -183,25 +189,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # N > 1 (untimed): the gathered results against a plain u16 gather of the same outputs
+    # N > 1 (untimed): the gathered results against a plain u16 gather of the same outputs, an eighth of
+    # the bases at a time -- rank 0 already holds world x 4.5 GB of rebuilt results next to its 229 GB index
     gather_ok = None
     if world > 1:
-        raw = [torch.empty(n_bases, dtype=torch.int16, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(d_pml[:n_bases].contiguous(), raw, dst=0)
-        rawc = [torch.empty(n_bases, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(d_cid[:n_bases].contiguous(), rawc, dst=0)
-        torch.cuda.synchronize()
-        if rank == 0:
-            if g_cid is not None:
-                gather_ok = all(bool(torch.equal(g_cid[r][:n_bases], rawc[r])) for r in range(world))
-            else:
-                got_c = pipe.gathered[-1]
-                gather_ok = all(bool(torch.equal(got_c[r], rawc[r])) for r in range(world))
-            if codecs:
-                gather_ok = gather_ok and all(bool(torch.equal(g_pml[r][:n_bases], raw[r])) for r in range(world))
-            else:
-                gp = pipe.gathered[0].view(torch.int16)
-                gather_ok = gather_ok and all(bool(torch.equal(gp[r], raw[r])) for r in range(world))
+        gather_ok = True if rank == 0 else None
+        n_slices = 8
+        for sl in range(n_slices):
+            lo, hi = n_bases * sl // n_slices, n_bases * (sl + 1) // n_slices
+            raw = [torch.empty(hi - lo, dtype=torch.int16, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_pml[lo:hi].contiguous(), raw, dst=0)
+            rawc = [torch.empty(hi - lo, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_cid[lo:hi].contiguous(), rawc, dst=0)
+            torch.cuda.synchronize()
+            if rank == 0:
+                got_c = g_cid if g_cid is not None else pipe.gathered[-1]
+                got_p = g_pml if codecs else pipe.gathered[0].view(torch.int16)
+                gather_ok = gather_ok and all(bool(torch.equal(got_c[r][lo:hi], rawc[r])) and bool(torch.equal(got_p[r][lo:hi], raw[r]))
+                                              for r in range(world))
             del raw, rawc
 
     kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
