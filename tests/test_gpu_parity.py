@@ -659,7 +659,7 @@ def test_granule_store_small_tables(pkg, oracle, tmp_path):
     oracle.OracleIndex(image.tobytes()).pml_query_files(str(fa), str(fa) + ".opml", str(fa) + ".ocid")
     (tmp_path / "tbl.col_pml").write_bytes(image.tobytes())
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for layout in (5, 4, 3, 2, 1):
+    for layout in (6, 5, 4, 3, 2, 1):
         fa2 = tmp_path / f"store_{layout}.fa"
         shutil.copy(fa, fa2)
         env = dict(os.environ, COLBWT_VMM_GRANULE_MB="2", COLBWT_VMM_MIN_MB="1", COLBWT_ALLOC_LOG="1", COLBWT_LAYOUT=str(layout))
